@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""Capture golden input/output vectors by running the REFERENCE's own classes.
+
+Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+Writes tests/golden/*.npz.  These files are data (inputs, explicit weights,
+expected outputs); no reference source travels.  The reference imports
+``torch_geometric.nn.MetaLayer`` (models/GNN.py:24), which is not installed and
+cannot be installed offline; MetaLayer does no arithmetic (two row gathers and
+a call order), so an in-memory module object that
+implements exactly that call contract is registered under that name before the
+reference module is imported.  ``torch_scatter`` is absent, so the reference
+selects its own ``index_add_`` fallback (models/GNN.py:9-21).
+
+Everything numerical below is computed by the reference's code: its
+``scatter_sum``, ``MLP``, ``EdgeProcessor``, ``NodeProcessor``,
+``build_GN_block``, ``GraphNet``, ``CombinedModel``, the training-step sequence
+of utils/train_model.py:37-42 and ``create_grid_edges_optimized``.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _register_metalayer():
+    tg = types.ModuleType("torch_geometric")
+    tgnn = types.ModuleType("torch_geometric.nn")
+
+    class MetaLayer(torch.nn.Module):
+        def __init__(self, edge_model=None, node_model=None, global_model=None):
+            super().__init__()
+            self.edge_model, self.node_model, self.global_model = edge_model, node_model, global_model
+
+        def forward(self, x, edge_index, edge_attr=None, u=None, batch=None):
+            row, col = edge_index[0], edge_index[1]
+            if self.edge_model is not None:
+                edge_attr = self.edge_model(x[row], x[col], edge_attr, u, batch if batch is None else batch[row])
+            if self.node_model is not None:
+                x = self.node_model(x, edge_index, edge_attr, u, batch)
+            return x, edge_attr, u
+
+    tgnn.MetaLayer = MetaLayer
+    tg.nn = tgnn
+    sys.modules["torch_geometric"] = tg
+    sys.modules["torch_geometric.nn"] = tgnn
+
+
+def _np(t):
+    return t.detach().cpu().numpy().copy()  # copy: optimizer steps update parameters in place
+
+
+def _sd(module, tag="sd/"):
+    return {tag + k: _np(v) for k, v in module.state_dict().items()}
+
+
+def _save(name, **arrays):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {name}: {os.path.getsize(path) / 1024:.1f} KiB, {len(arrays)} arrays")
+
+
+def random_graph(rng, n, e, ensure_empty=True):
+    """Directed multigraph with repeated destinations and (optionally) a few
+    nodes without in-edges; the last node always has an in-edge so that the
+    reference's dim_size inference (models/GNN.py:16-17) equals n."""
+    row = rng.integers(0, n, size=e)
+    lo = 3 if ensure_empty else 0  # nodes 0..2 never receive
+    col = rng.integers(lo, n, size=e)
+    col[-1] = n - 1
+    return np.stack([row, col]).astype(np.int64)
+
+
+def main():
+    sys.path.insert(0, REF)
+    _register_metalayer()
+    from models.GNN import (CombinedModel, EdgeProcessor, GraphNet, NodeProcessor, build_GN_block,
+                            scatter_sum)
+    from models.MLP import MLP
+    from utils.image_to_graph.image_to_graph_optimized import (create_grid_edges_optimized,
+                                                               image_to_graph_pixel_optimized)
+
+    rng = np.random.default_rng(20250824)
+
+    # ---- G1 scatter_sum ---------------------------------------------------
+    torch.manual_seed(1)
+    src = torch.randn(211, 8)
+    index = torch.from_numpy(random_graph(rng, 37, 211)[1])
+    src1d = torch.randn(211)
+    _save("g1_scatter.npz",
+          src=_np(src), index=_np(index),
+          out_infer=_np(scatter_sum(src, index, dim=0)),
+          out_dimsize40=_np(scatter_sum(src, index, dim=0, dim_size=40)),
+          src1d=_np(src1d), out_1d=_np(scatter_sum(src1d, index, dim=0)),
+          out_empty_shape=np.array(scatter_sum(torch.zeros(0, 8), torch.zeros(0, dtype=torch.long)).shape))
+
+    # ---- G2 MLP -------------------------------------------------------------
+    arrays = {}
+    torch.manual_seed(2)
+    xin = torch.randn(29, 7)
+    arrays["x"] = _np(xin)
+    for norm in ("LayerNorm", None):
+        for hl in (1, 2, 3):
+            m = MLP(7, 5, hidden_dim=16, hidden_layers=hl, norm_type=norm)
+            if norm is not None:  # non-trivial affine so gamma/beta are exercised
+                with torch.no_grad():
+                    m.model[-1].weight.uniform_(0.5, 1.5)
+                    m.model[-1].bias.uniform_(-0.5, 0.5)
+            tag = f"{'ln' if norm else 'nonorm'}_hl{hl}"
+            arrays.update(_sd(m, f"{tag}/sd/"))
+            arrays[f"{tag}/y"] = _np(m(xin))
+    # the .float() downcast of an fp64 input and the view(x.size(0), -1) flatten (models/MLP.py:46-47)
+    m = MLP(12, 4, hidden_dim=8, hidden_layers=2)
+    x3 = torch.randn(6, 3, 4, dtype=torch.float64)
+    arrays.update(_sd(m, "flat64/sd/"))
+    arrays["flat64/x"] = _np(x3)
+    arrays["flat64/y"] = _np(m(x3))
+    _save("g2_mlp.npz", **arrays)
+
+    # ---- G3 processors / GN block ------------------------------------------
+    torch.manual_seed(3)
+    n, e, dn, de = 37, 211, 16, 8
+    ei = torch.from_numpy(random_graph(rng, n, e))
+    x = torch.randn(n, dn)
+    ea = torch.randn(e, de)
+    ep = EdgeProcessor(dn, de, hidden_dim=24, hidden_layers=2)
+    npz = NodeProcessor(dn, de, hidden_dim=24, hidden_layers=2)
+    blk = build_GN_block(dn, de, hidden_dim_node=24, hidden_dim_edge=24)
+    e_out = ep(x[ei[0]], x[ei[1]], ea.clone())
+    n_out = npz(x, ei, ea)
+    bx, be, _ = blk(x, ei, ea.clone())
+    _save("g3_gnblock.npz", x=_np(x), edge_index=_np(ei), edge_attr=_np(ea),
+          edge_out=_np(e_out), node_out=_np(n_out), block_x=_np(bx), block_e=_np(be),
+          **_sd(ep, "ep/sd/"), **_sd(npz, "np/sd/"), **_sd(blk, "blk/sd/"))
+
+    # ---- G4 (i) tiny GraphNet, D=16, L=2 -----------------------------------
+    torch.manual_seed(4)
+    kw = dict(num_local_features=3, space_dim=2, out_channels=2, n_blocks=2, out_dim_node=16, out_dim_edge=16,
+              hidden_dim_node=16, hidden_dim_edge=16, hidden_dim_decoder=16,
+              hidden_dim_processor_node=16, hidden_dim_processor_edge=16)
+    g = GraphNet(**kw)
+    n, e = 53, 301
+    ei = torch.from_numpy(random_graph(rng, n, e))
+    x = torch.rand(n, 3)
+    pos = torch.rand(n, 2) * 32
+    _save("g4_graphnet_tiny.npz", x=_np(x), pos=_np(pos), edge_index=_np(ei), y=_np(g(x, pos, ei)),
+          kwargs_json=np.frombuffer(repr(kw).encode(), dtype=np.uint8), **_sd(g))
+
+    # ---- G4 (ii)/(iii) default model on the pixel graph of a shipped image --
+    img = os.path.join(REF, "static/muffin/img_4_880_32.jpg")
+    xi, posi, eii = image_to_graph_pixel_optimized(img, resize_value=32)
+    x = torch.tensor(xi, dtype=torch.float32)
+    pos = torch.tensor(posi, dtype=torch.float32)
+    ei = torch.tensor(eii, dtype=torch.long)
+    torch.manual_seed(5)
+    g = GraphNet(num_local_features=3, space_dim=2, out_channels=1, n_blocks=3)  # main.py:72
+    g.eval()
+    with torch.no_grad():
+        y = g(x, pos, ei)
+    # weights as float16-exact values would lose information; keep float32
+    _save("g4_graphnet_default.npz", x=_np(x), pos=_np(pos), edge_index=_np(ei), y=_np(y), **_sd(g))
+
+    ck = torch.load(os.path.join(REF, "weights/GNN/dim32_3block/best_model_epoch5.pth"), map_location="cpu",
+                    weights_only=True)
+    m = CombinedModel(GraphNet(num_local_features=3, space_dim=2, out_channels=1, n_blocks=3), num_nodes=1024, classes=2)
+    m.load_state_dict(ck)
+    m.eval()
+    with torch.no_grad():
+        y = m.graph_net(x, pos, ei)
+        logits = m((x, pos, ei))
+    _save("g4_graphnet_ckpt.npz", x=_np(x), pos=_np(pos), edge_index=_np(ei), y=_np(y), logits=_np(logits), **_sd(m))
+
+    # ---- G5 CombinedModel training step (utils/train_model.py:9-10,37-42) ---
+    torch.manual_seed(6)
+    kw = dict(num_local_features=3, space_dim=2, out_channels=1, n_blocks=2, out_dim_node=16, out_dim_edge=16,
+              hidden_dim_node=16, hidden_dim_edge=16, hidden_dim_decoder=16,
+              hidden_dim_processor_node=16, hidden_dim_processor_edge=16)
+    n, e = 37, 211
+    m = CombinedModel(GraphNet(**kw), num_nodes=n, classes=2)
+    ei = torch.from_numpy(random_graph(rng, n, e))
+    x = torch.rand(n, 3)
+    pos = torch.rand(n, 2) * 32
+    label = torch.tensor(1, dtype=torch.long)
+    before = _sd(m, "before/")
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    crit = torch.nn.CrossEntropyLoss()
+    logits = m((x, pos, ei))
+    loss = crit(logits, label)
+    opt.zero_grad()
+    loss.backward()
+    grads = {"grad/" + k: _np(p.grad) for k, p in m.named_parameters()}
+    opt.step()
+    _save("g5_train_step.npz", x=_np(x), pos=_np(pos), edge_index=_np(ei), label=_np(label), logits=_np(logits),
+          loss=_np(loss), kwargs_json=np.frombuffer(repr(kw).encode(), dtype=np.uint8),
+          **before, **grads, **_sd(m, "after/"))
+
+    # ---- G6 grid topology (utils/image_to_graph/image_to_graph_optimized.py:7-39)
+    arrays = {}
+    for (h, w) in ((2, 3), (4, 4), (32, 32), (5, 3)):
+        for diag in (False, True):
+            arrays[f"grid_{h}x{w}_{'diag' if diag else 'nodiag'}"] = create_grid_edges_optimized(h, w, diag).astype(np.int64)
+    _save("g6_grid_edges.npz", **arrays)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,109 @@
+"""Pins the CPU oracle (oracle/graphnet_oracle.py) to the golden vectors captured from the
+reference's own classes (tests/golden/make_golden.py).  CPU only.
+
+Tolerances: the oracle restates the same float32 arithmetic with differently-ordered
+ATen/numpy kernels, so results agree to a few ulp; 2e-6 absolute on O(1) values is the
+gate (SURVEY.md section 4 measured 3e-7 fp32 noise for the reference itself).
+"""
+import ast
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import graphnet_oracle as O
+from tests._util import load_golden, max_abs, sub_state_dict, t
+
+TOL = 2e-6
+
+
+def test_g1_scatter_sum():
+    g = load_golden("g1_scatter.npz")
+    src, index = t(g["src"]), t(g["index"])
+    out = O.scatter_sum(src, index, dim=0)
+    assert out.shape == g["out_infer"].shape
+    assert torch.equal(out, t(g["out_infer"]))  # same edge-ordered fp32 sums -> bit exact
+    assert torch.equal(O.scatter_sum(src, index, dim=0, dim_size=40), t(g["out_dimsize40"]))
+    assert torch.equal(O.scatter_sum_fast(src, index, 37), t(g["out_infer"]))
+    out1d = O.scatter_sum(t(g["src1d"]), index)
+    assert out1d.shape == (37, 1) and torch.equal(out1d, t(g["out_1d"]))
+    assert tuple(O.scatter_sum(torch.zeros(0, 8), torch.zeros(0, dtype=torch.long)).shape) == tuple(g["out_empty_shape"])
+    with pytest.raises(NotImplementedError):
+        O.scatter_sum(src, index, dim=1)
+
+
+@pytest.mark.parametrize("tag", [f"{n}_hl{h}" for n in ("ln", "nonorm") for h in (1, 2, 3)])
+def test_g2_mlp(tag):
+    g = load_golden("g2_mlp.npz")
+    sd = sub_state_dict(g, f"{tag}/sd/")
+    y = O.mlp_forward(sd, "", t(g["x"])) if False else O.mlp_forward({"m." + k: v for k, v in sd.items()}, "m", t(g["x"]))
+    assert max_abs(y, t(g[f"{tag}/y"])) < TOL
+
+
+def test_g2_mlp_flatten_and_downcast():
+    g = load_golden("g2_mlp.npz")
+    sd = {"m." + k: v for k, v in sub_state_dict(g, "flat64/sd/").items()}
+    y = O.mlp_forward(sd, "m", t(g["flat64/x"]))
+    assert y.dtype == torch.float32 and max_abs(y, t(g["flat64/y"])) < TOL
+
+
+def test_g3_processors_and_block():
+    g = load_golden("g3_gnblock.npz")
+    x, ei, ea = t(g["x"]), t(g["edge_index"]), t(g["edge_attr"])
+    ep = {"p." + k: v for k, v in sub_state_dict(g, "ep/sd/").items()}
+    npd = {"p." + k: v for k, v in sub_state_dict(g, "np/sd/").items()}
+    blk = {"b." + k: v for k, v in sub_state_dict(g, "blk/sd/").items()}
+    assert max_abs(O.edge_processor(ep, "p", x[ei[0]], x[ei[1]], ea), t(g["edge_out"])) < TOL
+    assert max_abs(O.node_processor(npd, "p", x, ei, ea), t(g["node_out"])) < 4 * TOL
+    bx, be = O.gn_block(blk, "b", x, ei, ea)
+    assert max_abs(bx, t(g["block_x"])) < 4 * TOL and max_abs(be, t(g["block_e"])) < TOL
+
+
+@pytest.mark.parametrize("name", ["g4_graphnet_tiny.npz", "g4_graphnet_default.npz"])
+def test_g4_graphnet(name):
+    g = load_golden(name)
+    sd = sub_state_dict(g, "sd/")
+    y = O.graphnet_forward(sd, t(g["x"]), t(g["pos"]), t(g["edge_index"]))
+    assert y.shape == g["y"].shape
+    assert max_abs(y, t(g["y"])) < 1e-5
+    # fp64 cross-check of the restatement itself (noise floor of the fp32 reference)
+    y64 = O.graphnet_forward(O.to_dtype(sd, torch.float64), t(g["x"]).double(), t(g["pos"]).double(), t(g["edge_index"]))
+    assert max_abs(y64, t(g["y"])) < 1e-5
+
+
+def test_g4_graphnet_shipped_checkpoint():
+    g = load_golden("g4_graphnet_ckpt.npz")
+    sd = sub_state_dict(g, "sd/")
+    assert len(sd) == 76 and sum(v.numel() for v in sd.values()) == 682339
+    x, pos, ei = t(g["x"]), t(g["pos"]), t(g["edge_index"])
+    y = O.graphnet_forward(sd, x, pos, ei, prefix="graph_net.")
+    assert max_abs(y, t(g["y"])) < 1e-5
+    assert max_abs(O.combined_forward(sd, x, pos, ei), t(g["logits"])) < 1e-5
+
+
+def test_g5_forward_and_loss():
+    g = load_golden("g5_train_step.npz")
+    sd = sub_state_dict(g, "before/")
+    logits = O.combined_forward(sd, t(g["x"]), t(g["pos"]), t(g["edge_index"]))
+    assert logits.shape == (2,) and max_abs(logits, t(g["logits"])) < TOL
+    # unbatched CrossEntropyLoss (utils/train_model.py:10,38): -log_softmax(logits)[label]
+    loss = -(logits - torch.logsumexp(logits, 0))[int(g["label"])]
+    assert abs(float(loss) - float(g["loss"])) < TOL
+    kw = ast.literal_eval(bytes(g["kwargs_json"]).decode())
+    assert kw["n_blocks"] == O.n_blocks_of(sd, "graph_net.")
+
+
+def test_g6_grid_edges():
+    g = load_golden("g6_grid_edges.npz")
+    for key, ref in g.items():
+        _, hw, diag = key.split("_")
+        h, w = (int(v) for v in hw.split("x"))
+        assert np.array_equal(O.grid_edge_index(h, w, diag == "diag"), ref), key
+    assert O.grid_edge_index(2, 3).tolist() == [[0, 1, 3, 4, 0, 1, 2], [1, 2, 4, 5, 3, 4, 5]]
+
+
+def test_edge_features_l1():
+    pos = torch.tensor([[0.0, 0.0], [1.0, 3.0], [4.0, -1.0]])
+    ei = torch.tensor([[0, 1, 2], [1, 2, 0]])
+    e = O.edge_features(pos, ei)
+    assert torch.equal(e, torch.tensor([[1.0, 3.0, 4.0], [3.0, -4.0, 7.0], [-4.0, 1.0, 5.0]]))
