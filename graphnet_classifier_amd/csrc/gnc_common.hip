@@ -1,0 +1,23 @@
+// Diagnostics entry points of the C ABI (include/gnc_hip.h).
+#include <stdarg.h>
+#include <string.h>
+
+#include "gnc_common.h"
+
+namespace gnc {
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+}  // namespace gnc
+
+extern "C" {
+int gnc_abi_version(void) { return GNC_ABI_VERSION; }
+const char* gnc_last_error_string(void) { return gnc::g_err; }
+const char* gnc_target_arch(void) { return "gfx950"; }
+size_t gnc_sizeof_mlp_desc(void) { return sizeof(gnc_mlp_desc_t); }
+}

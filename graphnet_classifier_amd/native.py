@@ -1,0 +1,253 @@
+"""ctypes binding of ``libgnc_hip.so`` (C ABI: ``include/gnc_hip.h``).
+
+PyTorch is used for device memory and streams only: every call below passes raw
+``data_ptr()`` values and the current HIP stream to the library.  There is NO
+fallback: if the shared library is missing or a call fails, a ``RuntimeError``
+is raised -- the product path never silently routes around the HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_size_t, c_void_p
+
+import torch
+
+LIB_NAME = "libgnc_hip.so"
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+
+GNC_MAX_SEGMENTS = 4
+GNC_MAX_LINEAR = 8
+ABI_VERSION = 1
+
+ACTIVATIONS = {  # nn.<Name> accepted by the reference's MLP(activation=...) (models/MLP.py:21)
+    "ReLU": 0, "Identity": 1, "Tanh": 2, "Sigmoid": 3, "SiLU": 4, "GELU": 5, "LeakyReLU": 6, "ELU": 7,
+}
+
+# every symbol include/gnc_hip.h declares: (restype, argtypes)
+_SIGNATURES = {
+    "gnc_abi_version": (c_int32, []),
+    "gnc_last_error_string": (c_char_p, []),
+    "gnc_target_arch": (c_char_p, []),
+    "gnc_csr_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "gnc_csr_build": (c_int32, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "gnc_permute_index_i64_i32": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "gnc_scatter_sum_csr_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p,
+                                          c_int64, c_void_p]),
+    "gnc_gather_rows_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p]),
+    "gnc_edge_features_f32": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "gnc_sizeof_mlp_desc": (c_size_t, []),
+    "gnc_mlp_supported": (c_int32, [c_void_p]),
+    "gnc_mlp_forward_f32": (c_int32, [c_void_p, c_void_p]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+class MlpSegment(Structure):
+    _fields_ = [("ptr", c_void_p), ("index", c_void_p), ("width", c_int32), ("ld", c_int32)]
+
+
+class MlpDesc(Structure):
+    _fields_ = [
+        ("num_segments", c_int32), ("num_linear", c_int32), ("activation", c_int32), ("act_param", c_float),
+        ("seg", MlpSegment * GNC_MAX_SEGMENTS),
+        ("weight", c_void_p * GNC_MAX_LINEAR), ("bias", c_void_p * GNC_MAX_LINEAR),
+        ("in_dim", c_int32 * GNC_MAX_LINEAR), ("out_dim", c_int32 * GNC_MAX_LINEAR),
+        ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ln_eps", c_float),
+        ("residual", c_void_p), ("ld_residual", c_int32),
+        ("out", c_void_p), ("ld_out", c_int32),
+        ("rows", c_int64),
+    ]
+
+
+_lib = None
+
+
+def load_library() -> ctypes.CDLL:
+    """Load the in-tree shared library (torch is imported first so that its HIP runtime is
+    the one already mapped).  Raises RuntimeError when it is missing or has the wrong ABI."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C graphnet_classifier_amd/csrc`.  There is no CPU/PyTorch fallback for the hot path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here means the header and the library disagree
+        fn.restype = res
+        fn.argtypes = args
+    if lib.gnc_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{LIB_NAME}: ABI version {lib.gnc_abi_version()} != expected {ABI_VERSION}")
+    if lib.gnc_sizeof_mlp_desc() != ctypes.sizeof(MlpDesc):
+        raise RuntimeError(f"{LIB_NAME}: gnc_mlp_desc_t is {lib.gnc_sizeof_mlp_desc()} bytes in C but "
+                           f"{ctypes.sizeof(MlpDesc)} in the ctypes binding")
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load_library().gnc_last_error_string()
+        raise RuntimeError(f"{what} failed with code {rc}: {msg.decode() if msg else ''}")
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _require_cuda(*tensors: torch.Tensor) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("graphnet_classifier_amd: the hot path runs on the GPU only; got a CPU tensor "
+                               "(there is deliberately no CPU fallback)")
+
+
+def _rowmajor(t: torch.Tensor) -> torch.Tensor:
+    """2-D fp32 tensor with unit column stride (row stride may exceed the width)."""
+    if t.dtype != torch.float32:
+        raise TypeError(f"expected float32, got {t.dtype}")
+    if t.dim() != 2:
+        raise ValueError(f"expected a 2-D tensor, got shape {tuple(t.shape)}")
+    if t.size(1) > 0 and t.stride(1) != 1 or (t.size(0) > 1 and t.stride(0) < t.size(1)):
+        t = t.contiguous()
+    return t
+
+
+def _ld(t: torch.Tensor) -> int:
+    return t.stride(0) if t.size(0) > 1 else max(t.size(1), 1)
+
+
+# --------------------------------------------------------------------------- topology
+def csr_build(index: torch.Tensor, num_nodes: int):
+    """index [E] int64 (device) -> (rowptr int32 [N+1], perm int32 [E], status int32 [1])."""
+    lib = load_library()
+    _require_cuda(index)
+    if index.dtype != torch.int64:
+        index = index.long()
+    index = index.contiguous()
+    e = index.numel()
+    dev = index.device
+    rowptr = torch.empty(num_nodes + 1, dtype=torch.int32, device=dev)
+    perm = torch.empty(e, dtype=torch.int32, device=dev)
+    status = torch.empty(1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        nbytes = lib.gnc_csr_workspace_bytes(num_nodes, e)
+        if nbytes == 0:
+            _check(-1, "gnc_csr_workspace_bytes")
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _check(lib.gnc_csr_build(index.data_ptr(), e, num_nodes, rowptr.data_ptr(), perm.data_ptr(), status.data_ptr(),
+                                 ws.data_ptr(), nbytes, _stream(index)), "gnc_csr_build")
+    return rowptr, perm, status
+
+
+def permute_index(src: torch.Tensor, perm: torch.Tensor | None) -> torch.Tensor:
+    """int64 [E] -> int32 [E], reordered by perm (sorted position -> original edge)."""
+    lib = load_library()
+    _require_cuda(src)
+    src = src.contiguous()
+    out = torch.empty(src.numel(), dtype=torch.int32, device=src.device)
+    with torch.cuda.device(src.device):
+        _check(lib.gnc_permute_index_i64_i32(src.data_ptr(), perm.data_ptr() if perm is not None else None, src.numel(),
+                                             out.data_ptr(), _stream(src)), "gnc_permute_index_i64_i32")
+    return out
+
+
+# --------------------------------------------------------------------------- K1 / K2 / K6
+def scatter_sum_csr(src: torch.Tensor, rowptr: torch.Tensor, perm: torch.Tensor | None, num_nodes: int,
+                    out: torch.Tensor | None = None) -> torch.Tensor:
+    lib = load_library()
+    _require_cuda(src, rowptr)
+    src = _rowmajor(src)
+    e, d = src.shape
+    if out is None:
+        out = torch.empty(num_nodes, d, dtype=torch.float32, device=src.device)
+    with torch.cuda.device(src.device):
+        _check(lib.gnc_scatter_sum_csr_f32(src.data_ptr(), _ld(src), rowptr.data_ptr(),
+                                           perm.data_ptr() if perm is not None else None, num_nodes, e, d,
+                                           out.data_ptr(), _ld(out), _stream(src)), "gnc_scatter_sum_csr_f32")
+    return out
+
+
+def gather_rows(table: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
+    lib = load_library()
+    _require_cuda(table, index)
+    table = _rowmajor(table)
+    if index.dtype != torch.int32:
+        raise TypeError("gather_rows expects an int32 index")
+    n, d = index.numel(), table.size(1)
+    out = torch.empty(n, d, dtype=torch.float32, device=table.device)
+    with torch.cuda.device(table.device):
+        _check(lib.gnc_gather_rows_f32(table.data_ptr(), _ld(table), index.data_ptr(), n, d, out.data_ptr(), _ld(out),
+                                       _stream(table)), "gnc_gather_rows_f32")
+    return out
+
+
+def edge_features(pos: torch.Tensor, src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    lib = load_library()
+    _require_cuda(pos, src, dst)
+    pos = pos.float().contiguous()
+    e, sd = src.numel(), pos.size(1)
+    out = torch.empty(e, sd + 1, dtype=torch.float32, device=pos.device)
+    with torch.cuda.device(pos.device):
+        _check(lib.gnc_edge_features_f32(pos.data_ptr(), sd, src.data_ptr(), dst.data_ptr(), e, out.data_ptr(),
+                                         _stream(pos)), "gnc_edge_features_f32")
+    return out
+
+
+# --------------------------------------------------------------------------- K4
+def make_mlp_desc(segments, weights, biases, ln, activation: str, act_param: float, residual, out, rows: int):
+    """Fill a gnc_mlp_desc_t.  ``segments`` = [(table, index_or_None, width)], tensors must stay
+    alive until the call returns (they are enqueued on the current stream)."""
+    if len(segments) > GNC_MAX_SEGMENTS or not (2 <= len(weights) <= GNC_MAX_LINEAR):
+        raise NotImplementedError(f"MLP with {len(segments)} segments / {len(weights)} Linear layers is outside the HIP kernel")
+    if activation not in ACTIVATIONS:
+        raise NotImplementedError(f"activation nn.{activation} has no HIP kernel (supported: {sorted(ACTIVATIONS)})")
+    d = MlpDesc()
+    d.num_segments = len(segments)
+    d.num_linear = len(weights)
+    d.activation = ACTIVATIONS[activation]
+    d.act_param = act_param
+    for s, (table, index, width) in enumerate(segments):
+        d.seg[s].ptr = table.data_ptr()
+        d.seg[s].index = index.data_ptr() if index is not None else None
+        d.seg[s].width = width
+        d.seg[s].ld = _ld(table)
+    for l, (w, b) in enumerate(zip(weights, biases)):
+        d.weight[l] = w.data_ptr()
+        d.bias[l] = b.data_ptr() if b is not None else None
+        d.out_dim[l], d.in_dim[l] = w.shape
+    if ln is not None:
+        d.ln_gamma, d.ln_beta, d.ln_eps = ln[0].data_ptr(), ln[1].data_ptr(), ln[2]
+    if residual is not None:
+        d.residual, d.ld_residual = residual.data_ptr(), _ld(residual)
+    d.out, d.ld_out = out.data_ptr(), _ld(out)
+    d.rows = rows
+    return d
+
+
+def mlp_forward(segments, weights, biases, ln=None, activation: str = "ReLU", act_param: float = 0.0,
+                residual: torch.Tensor | None = None, rows: int | None = None) -> torch.Tensor:
+    """Fused MLP.  segments: list of (table [*, w] fp32, index int32 [rows] | None)."""
+    lib = load_library()
+    segs = []
+    for table, index in segments:
+        _require_cuda(table, index)
+        table = _rowmajor(table)
+        if index is not None and index.dtype != torch.int32:
+            raise TypeError("segment index must be int32")
+        segs.append((table, index, table.size(1)))
+    if rows is None:
+        t0, i0, _ = segs[0]
+        rows = i0.numel() if i0 is not None else t0.size(0)
+    weights = [w.contiguous() for w in weights]
+    biases = [b.contiguous() if b is not None else None for b in biases]
+    dev = segs[0][0].device
+    out = torch.empty(rows, weights[-1].size(0), dtype=torch.float32, device=dev)
+    if residual is not None:
+        residual = _rowmajor(residual)
+    desc = make_mlp_desc(segs, weights, biases, ln, activation, act_param, residual, out, rows)
+    with torch.cuda.device(dev):
+        _check(lib.gnc_mlp_forward_f32(ctypes.byref(desc), _stream(out)), "gnc_mlp_forward_f32")
+    return out

@@ -1,0 +1,156 @@
+/*
+ * gnc_hip.h -- C ABI of the MI355X (gfx950) message-passing engine that stands behind the
+ * GraphNet forward hot path of alexisvannson/GraphNet_Classifier.
+ *
+ * This is the drop-in boundary.  The reference has no FFI of its own:
+ * its narrowest seam is the module-level Python name `scatter_sum` bound at import
+ * (reference models/GNN.py:4-21, where an optional C++ extension or an `index_add_` fallback
+ * is chosen) plus the `torch.nn.Module` forward methods of `MLP`, `EdgeProcessor`,
+ * `NodeProcessor`, `GraphProcessor` and `GraphNet`.  Each entry point below names the
+ * reference line(s) whose work it replaces.  A maintainer of the reference binds these with
+ * `ctypes` (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless marked host;
+ *   - `stream` is a `hipStream_t` passed as `void*`; nothing here synchronises the stream,
+ *     allocates, or frees: outputs and workspaces are caller-allocated (the Python side uses
+ *     torch's caching allocator) so calls can be captured into a hipGraph;
+ *   - return value: 0 = GNC_OK, negative = error (see enum); `gnc_last_error_string()` gives
+ *     a thread-local description of the last failure on the calling thread;
+ *   - matrices are row-major fp32; `ld*` are leading dimensions in ELEMENTS;
+ *   - indices are int32 inside the engine; the int64 `edge_index` of the reference
+ *     (utils/dataloader.py:51) is narrowed once, by `gnc_csr_build`.
+ */
+#ifndef GNC_HIP_H
+#define GNC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GNC_ABI_VERSION 1
+
+enum {
+  GNC_OK = 0,
+  GNC_ERR_INVALID_ARGUMENT = -1, /* null pointer, negative size, misaligned buffer ...      */
+  GNC_ERR_UNSUPPORTED = -2,      /* shape outside what the kernels are instantiated for      */
+  GNC_ERR_WORKSPACE = -3,        /* workspace smaller than gnc_*_workspace_bytes() reports   */
+  GNC_ERR_HIP = -4               /* a HIP runtime call or a kernel launch failed             */
+};
+
+#define GNC_MAX_SEGMENTS 4 /* concat segments feeding the first Linear of an MLP */
+#define GNC_MAX_LINEAR 8   /* Linear layers in one MLP (hidden_layers + 1)       */
+
+enum { GNC_ACT_RELU = 0, GNC_ACT_IDENTITY = 1, GNC_ACT_TANH = 2, GNC_ACT_SIGMOID = 3,
+       GNC_ACT_SILU = 4, GNC_ACT_GELU = 5, GNC_ACT_LEAKY_RELU = 6, GNC_ACT_ELU = 7 };
+
+/* ---- diagnostics --------------------------------------------------------------------- */
+int gnc_abi_version(void);
+const char* gnc_last_error_string(void);
+/* Name of the device code object target this library was built for ("gfx950"). */
+const char* gnc_target_arch(void);
+
+/* ---- topology: edge list -> destination-sorted CSR ------------------------------------
+ * Replaces nothing the reference does explicitly: the reference re-derives "who sends to
+ * node v" inside every `index_add_` (models/GNN.py:18-20).  Here the destination column of
+ * `edge_index` (models/GNN.py:98 `_, col = edge_index`) is sorted once per topology.
+ *
+ *   index   [E] int64   destination (or source) node id per edge, any order
+ *   rowptr  [N+1] int32 out: edges of node v are sorted positions rowptr[v] .. rowptr[v+1]-1
+ *   perm    [E] int32   out: perm[k] = ORIGINAL edge id at sorted position k.  The sort is
+ *                       stable, so inside a segment edges keep their original order and the
+ *                       per-destination summation order equals the reference's edge order.
+ *   status  [1] int32   out: 0, or 1 if any index was outside [0, N) (such edges are dropped
+ *                       instead of faulting; the reference raises IndexError there)
+ */
+size_t gnc_csr_workspace_bytes(int64_t num_nodes, int64_t num_edges);
+int gnc_csr_build(const int64_t* index, int64_t num_edges, int64_t num_nodes,
+                  int32_t* rowptr, int32_t* perm, int32_t* status,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* out[k] = (int32) src[perm[k]]   -- narrows and reorders an int64 edge_index row. */
+int gnc_permute_index_i64_i32(const int64_t* src, const int32_t* perm, int64_t n, int32_t* out, void* stream);
+
+/* ---- K1: scatter-sum neighbourhood aggregation ------------------------------------------
+ * Replaces `scatter_sum(edge_attr, col, dim=0)` (models/GNN.py:99 -> :11-21):
+ *   out[v, :] = sum over sorted positions k in [rowptr[v], rowptr[v+1]) of src[row(k), :]
+ * with row(k) = perm[k], or k itself when `perm` is NULL (messages already stored in
+ * destination-sorted order).  No atomics: each destination is summed by one lane group in
+ * ascending k, so the result is bitwise reproducible and every out row is written
+ * (zero for a node without in-edges), no memset needed.
+ */
+int gnc_scatter_sum_csr_f32(const float* src, int64_t ld_src, const int32_t* rowptr, const int32_t* perm,
+                            int64_t num_nodes, int64_t num_edges, int32_t feat_dim,
+                            float* out, int64_t ld_out, void* stream);
+
+/* ---- K2: row gather -----------------------------------------------------------------------
+ * Replaces `x[row]`, `x[col]` of PyG MetaLayer.forward (called at models/GNN.py:215) and is the
+ * backward of K1:  out[r, :] = table[index[r], :].
+ */
+int gnc_gather_rows_f32(const float* table, int64_t ld_table, const int32_t* index, int64_t num_rows,
+                        int32_t feat_dim, float* out, int64_t ld_out, void* stream);
+
+/* ---- K6: edge features ------------------------------------------------------------------
+ * Replaces models/GNN.py:299-302:  rel = pos[dst[e]] - pos[src[e]];  out[e] = [rel, sum|rel|].
+ * pos is [N, space_dim]; out is [E, space_dim + 1].
+ */
+int gnc_edge_features_f32(const float* pos, int32_t space_dim, const int32_t* src, const int32_t* dst,
+                          int64_t num_edges, float* out, void* stream);
+
+/* ---- K4: fused MLP ----------------------------------------------------------------------
+ * Replaces `MLP.forward` (models/MLP.py:45-47 over the Sequential built at :24-37) together
+ * with the `torch.cat` in front of it and the residual add behind it in the processors
+ * (models/GNN.py:58-62 and :100-102):
+ *
+ *   in[r]  = concat over segments s of  seg[s].ptr[ row_s(r), 0:width_s ]      (never materialised)
+ *            row_s(r) = seg[s].index[r] if index != NULL else r                 (fused gather, K2+K3)
+ *   h      = act(in  W0^T + b0);  h = act(h Wl^T + bl) ...;  y = h W_last^T + b_last
+ *   y      = LayerNorm(y) * gamma + beta        if ln_gamma != NULL  (eps = ln_eps)
+ *   out[r] = y + residual[r]                    if residual != NULL
+ *
+ * Weights are nn.Linear layout [out_dim, in_dim] row-major (state-dict tensors are passed
+ * as they are).  fp32 in, fp32 MFMA (v_mfma_f32_32x32x2_f32), fp32 out.
+ * Limits: hidden widths and out width <= 256, 2 <= num_linear <= GNC_MAX_LINEAR, all
+ * hidden layers the same width (true by construction in models/MLP.py:24-27).
+ */
+typedef struct gnc_mlp_segment {
+  const float* ptr;     /* [*, ld] table                                   */
+  const int32_t* index; /* NULL, or [rows] row ids into the table          */
+  int32_t width;        /* columns taken from the table                    */
+  int32_t ld;           /* leading dimension of the table (elements)       */
+} gnc_mlp_segment_t;
+
+typedef struct gnc_mlp_desc {
+  int32_t num_segments;
+  int32_t num_linear;
+  int32_t activation;   /* GNC_ACT_*                                       */
+  float act_param;      /* negative slope / alpha for LEAKY_RELU / ELU     */
+  gnc_mlp_segment_t seg[GNC_MAX_SEGMENTS];
+  const float* weight[GNC_MAX_LINEAR]; /* [out_dim[l], in_dim[l]]          */
+  const float* bias[GNC_MAX_LINEAR];   /* [out_dim[l]] or NULL             */
+  int32_t in_dim[GNC_MAX_LINEAR];
+  int32_t out_dim[GNC_MAX_LINEAR];
+  const float* ln_gamma; /* NULL = no LayerNorm                            */
+  const float* ln_beta;
+  float ln_eps;
+  const float* residual; /* NULL, or [rows, ld_residual]                   */
+  int32_t ld_residual;
+  float* out;            /* [rows, ld_out]                                 */
+  int32_t ld_out;
+  int64_t rows;
+} gnc_mlp_desc_t;
+
+/* 0 if gnc_mlp_forward_f32 can run this description, GNC_ERR_UNSUPPORTED otherwise
+ * (pointers are not inspected, only the shape fields). */
+/* sizeof(gnc_mlp_desc_t) as compiled into the library, for binding cross-checks. */
+size_t gnc_sizeof_mlp_desc(void);
+int gnc_mlp_supported(const gnc_mlp_desc_t* desc /* host */);
+int gnc_mlp_forward_f32(const gnc_mlp_desc_t* desc /* host */, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNC_HIP_H */

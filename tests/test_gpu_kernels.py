@@ -1,0 +1,237 @@
+"""GPU parity tests of the individual HIP kernels, called through the C ABI
+(graphnet_classifier_amd.native -> libgnc_hip.so), against the CPU oracle.
+
+Bars: index work (CSR build) and the scatter-sum are checked BIT-EXACT (the CSR segment is
+summed in the reference's edge order); the fp32-MFMA MLP is checked to 1e-5 absolute on O(1)
+values (north_star tolerance), typically ~1e-6.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import graphnet_oracle as O
+from tests._util import load_golden, max_abs, sub_state_dict, t
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def native():
+    from graphnet_classifier_amd import native as n
+    n.load_library()
+    return n
+
+
+def _random_index(rng, n, e, empty_frac=0.1):
+    idx = rng.integers(int(n * empty_frac), n, size=e)
+    return torch.from_numpy(idx.astype(np.int64))
+
+
+# ------------------------------------------------------------------ topology
+@pytest.mark.parametrize("n,e", [(1, 1), (7, 0), (37, 211), (1000, 12345), (5000, 300), (160, 1600), (100003, 1000003)])
+def test_csr_build_matches_stable_sort(native, n, e):
+    rng = np.random.default_rng(n * 7 + e)
+    index = _random_index(rng, n, e) if e else torch.zeros(0, dtype=torch.int64)
+    rowptr, perm, status = native.csr_build(index.to(DEV), n)
+    assert int(status.item()) == 0
+    order = np.argsort(index.numpy(), kind="stable")
+    counts = np.bincount(index.numpy(), minlength=n)
+    ref_rowptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    assert np.array_equal(rowptr.cpu().numpy(), ref_rowptr)
+    assert np.array_equal(perm.cpu().numpy(), order.astype(np.int32))
+
+
+def test_csr_build_flags_out_of_range(native):
+    index = torch.tensor([0, 5, 2, -1, 9, 3], dtype=torch.int64)
+    rowptr, perm, status = native.csr_build(index.to(DEV), 5)
+    assert int(status.item()) == 1
+    # valid edges (0, 2, 3) still form a correct CSR; invalid ones sit behind rowptr[N]
+    assert rowptr.cpu().tolist() == [0, 1, 1, 2, 3, 3]
+    assert perm.cpu().tolist()[:3] == [0, 2, 5]
+
+
+# ------------------------------------------------------------------ K1 scatter-sum
+@pytest.mark.parametrize("d", [1, 3, 4, 8, 12, 16, 32, 64, 100, 128, 256, 260])
+@pytest.mark.parametrize("use_perm", [True, False])
+def test_scatter_sum_bit_exact(native, d, use_perm):
+    rng = np.random.default_rng(d)
+    n, e = 997, 9001
+    index = _random_index(rng, n, e)
+    src = torch.from_numpy(rng.standard_normal((e, d)).astype(np.float32))
+    rowptr, perm, _ = native.csr_build(index.to(DEV), n)
+    if use_perm:
+        out = native.scatter_sum_csr(src.to(DEV), rowptr, perm, n)
+    else:  # messages already in destination-sorted order
+        out = native.scatter_sum_csr(src.to(DEV)[perm.long()], rowptr, None, n)
+    ref = O.scatter_sum_fast(src, index, n)
+    assert torch.equal(out.cpu(), ref)
+    # run-to-run determinism
+    out2 = native.scatter_sum_csr(src.to(DEV), rowptr, perm, n) if use_perm else out
+    assert torch.equal(out, out2)
+
+
+def test_scatter_sum_golden_g1(native):
+    g = load_golden("g1_scatter.npz")
+    src, index = t(g["src"], DEV), t(g["index"], DEV)
+    rowptr, perm, _ = native.csr_build(index, 37)
+    assert torch.equal(native.scatter_sum_csr(src, rowptr, perm, 37).cpu(), t(g["out_infer"]))
+    rowptr40, perm40, _ = native.csr_build(index, 40)
+    assert torch.equal(native.scatter_sum_csr(src, rowptr40, perm40, 40).cpu(), t(g["out_dimsize40"]))
+
+
+def test_scatter_sum_skewed_degrees(native):
+    """One hub destination with thousands of in-edges next to empty and degree-1 nodes."""
+    rng = np.random.default_rng(5)
+    n, e, d = 300, 20000, 64
+    idx = rng.integers(0, n, size=e)
+    idx[: e // 2] = 17
+    index = torch.from_numpy(idx.astype(np.int64))
+    src = torch.from_numpy(rng.standard_normal((e, d)).astype(np.float32))
+    rowptr, perm, _ = native.csr_build(index.to(DEV), n)
+    out = native.scatter_sum_csr(src.to(DEV), rowptr, perm, n)
+    assert torch.equal(out.cpu(), O.scatter_sum_fast(src, index, n))
+
+
+def test_scatter_sum_strided_rows(native):
+    """src/out given as column slices of wider buffers (leading dimension > width)."""
+    rng = np.random.default_rng(6)
+    n, e, d = 257, 3000, 64
+    index = _random_index(rng, n, e)
+    wide = torch.from_numpy(rng.standard_normal((e, 192)).astype(np.float32)).to(DEV)
+    rowptr, perm, _ = native.csr_build(index.to(DEV), n)
+    out = native.scatter_sum_csr(wide[:, 64:128], rowptr, perm, n)
+    assert torch.equal(out.cpu(), O.scatter_sum_fast(wide[:, 64:128].cpu().contiguous(), index, n))
+
+
+# ------------------------------------------------------------------ K2 / K6
+@pytest.mark.parametrize("d", [1, 3, 16, 64, 128, 200, 256])
+def test_gather_rows(native, d):
+    rng = np.random.default_rng(d + 100)
+    n, e = 513, 7777
+    table = torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32))
+    idx = torch.from_numpy(rng.integers(0, n, size=e).astype(np.int32))
+    out = native.gather_rows(table.to(DEV), idx.to(DEV))
+    assert torch.equal(out.cpu(), table[idx.long()])
+
+
+@pytest.mark.parametrize("space_dim", [1, 2, 3])
+def test_edge_features(native, space_dim):
+    rng = np.random.default_rng(space_dim)
+    n, e = 211, 3001
+    pos = torch.from_numpy((rng.random((n, space_dim)) * 32).astype(np.float32))
+    ei = torch.from_numpy(rng.integers(0, n, size=(2, e)).astype(np.int64))
+    out = native.edge_features(pos.to(DEV), ei[0].int().to(DEV), ei[1].int().to(DEV))
+    ref = O.edge_features(pos, ei)
+    assert max_abs(out.cpu(), ref) <= 4e-6  # |.|-sum order may differ for space_dim == 3
+    assert torch.equal(out.cpu()[:, :space_dim], ref[:, :space_dim])
+
+
+# ------------------------------------------------------------------ K4 fused MLP
+def _mlp_sd(rng, in_dim, hidden, out_dim, hidden_layers, ln):
+    dims = [in_dim] + [hidden] * hidden_layers + [out_dim]
+    sd, i = {}, 0
+    for a, b in zip(dims[:-1], dims[1:]):
+        bound = 1.0 / np.sqrt(a)
+        sd[f"m.model.{i}.weight"] = torch.from_numpy(rng.uniform(-bound, bound, (b, a)).astype(np.float32))
+        sd[f"m.model.{i}.bias"] = torch.from_numpy(rng.uniform(-bound, bound, (b,)).astype(np.float32))
+        i += 2
+    if ln:
+        sd[f"m.model.{i - 1}.weight"] = torch.from_numpy(rng.uniform(0.5, 1.5, (out_dim,)).astype(np.float32))
+        sd[f"m.model.{i - 1}.bias"] = torch.from_numpy(rng.uniform(-0.5, 0.5, (out_dim,)).astype(np.float32))
+    return sd
+
+
+def _run_mlp(native, sd, segments, residual=None, activation="ReLU"):
+    ws = [k for k in sd if k.endswith("weight") and sd[k].ndim == 2]
+    ws.sort(key=lambda k: int(k.split(".")[2]))
+    weights = [sd[k].to(DEV) for k in ws]
+    biases = [sd[k.replace("weight", "bias")].to(DEV) for k in ws]
+    lnk = [k for k in sd if k.endswith("weight") and sd[k].ndim == 1]
+    ln = (sd[lnk[0]].to(DEV), sd[lnk[0].replace("weight", "bias")].to(DEV), 1e-5) if lnk else None
+    segs = [(tab.to(DEV), idx.to(DEV) if idx is not None else None) for tab, idx in segments]
+    return native.mlp_forward(segs, weights, biases, ln=ln, activation=activation,
+                              residual=residual.to(DEV) if residual is not None else None)
+
+
+@pytest.mark.parametrize("tag", [f"{n}_hl{h}" for n in ("ln", "nonorm") for h in (1, 2, 3)])
+def test_mlp_golden_g2(native, tag):
+    g = load_golden("g2_mlp.npz")
+    sd = {"m." + k: v for k, v in sub_state_dict(g, f"{tag}/sd/").items()}
+    y = _run_mlp(native, sd, [(t(g["x"]), None)])
+    assert max_abs(y.cpu(), t(g[f"{tag}/y"])) < 1e-5
+
+
+@pytest.mark.parametrize("rows", [1, 31, 32, 33, 127, 128, 129, 1000])
+def test_mlp_row_tails(native, rows):
+    rng = np.random.default_rng(rows)
+    sd = _mlp_sd(rng, 64, 64, 64, 2, True)
+    x = torch.from_numpy(rng.standard_normal((rows, 64)).astype(np.float32))
+    y = _run_mlp(native, sd, [(x, None)], residual=x)
+    ref = O.mlp_forward(sd, "m", x) + x
+    assert y.shape == ref.shape and max_abs(y.cpu(), ref) < 1e-5
+
+
+@pytest.mark.parametrize("in_dim,hidden,out_dim,hl,ln", [
+    (3, 128, 128, 2, True),      # node / edge encoder (main.py:72 defaults)
+    (3, 64, 64, 2, True),
+    (128, 128, 1, 2, False),     # node decoder
+    (64, 64, 1, 2, False),
+    (7, 16, 5, 1, True),
+    (50, 48, 40, 3, True),       # nothing a multiple of 32
+    (96, 96, 96, 2, False),
+    (256, 256, 256, 2, True),    # config 5 width
+    (130, 200, 70, 2, True),
+    (64, 32, 256, 2, True),      # out wider than hidden
+])
+def test_mlp_shapes(native, in_dim, hidden, out_dim, hl, ln):
+    rng = np.random.default_rng(in_dim * 1000 + hidden + out_dim)
+    rows = 777
+    sd = _mlp_sd(rng, in_dim, hidden, out_dim, hl, ln)
+    x = torch.from_numpy(rng.standard_normal((rows, in_dim)).astype(np.float32))
+    y = _run_mlp(native, sd, [(x, None)])
+    ref = O.mlp_forward(sd, "m", x)
+    assert max_abs(y.cpu(), ref) < 1e-5
+
+
+@pytest.mark.parametrize("d", [16, 64, 128, 256])
+def test_mlp_edge_processor_fused_gather_concat_residual(native, d):
+    """EdgeProcessor (models/GNN.py:57-64): MLP(cat[x[row], x[col], e]) + e with the gathers,
+    the concat and the residual fused into the kernel."""
+    rng = np.random.default_rng(d)
+    n, e = 301, 2111
+    sd = _mlp_sd(rng, 3 * d, d, d, 2, True)
+    x = torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32))
+    ea = torch.from_numpy(rng.standard_normal((e, d)).astype(np.float32))
+    ei = torch.from_numpy(rng.integers(0, n, size=(2, e)).astype(np.int64))
+    y = _run_mlp(native, sd, [(x, ei[0].int()), (x, ei[1].int()), (ea, None)], residual=ea)
+    ref = O.mlp_forward(sd, "m", torch.cat([x[ei[0]], x[ei[1]], ea], -1)) + ea
+    assert max_abs(y.cpu(), ref) < 1e-5
+
+
+@pytest.mark.parametrize("act", ["Tanh", "Sigmoid", "SiLU", "GELU", "LeakyReLU", "ELU", "Identity"])
+def test_mlp_other_activations(native, act):
+    rng = np.random.default_rng(11)
+    sd = _mlp_sd(rng, 20, 32, 8, 2, True)
+    x = torch.from_numpy(rng.standard_normal((100, 20)).astype(np.float32))
+    ws = [sd[f"m.model.{i}.weight"].to(DEV) for i in (0, 2, 4)]
+    bs = [sd[f"m.model.{i}.bias"].to(DEV) for i in (0, 2, 4)]
+    ln = (sd["m.model.5.weight"].to(DEV), sd["m.model.5.bias"].to(DEV), 1e-5)
+    p = 0.01 if act == "LeakyReLU" else 1.0
+    y = native.mlp_forward([(x.to(DEV), None)], ws, bs, ln=ln, activation=act, act_param=p)
+    f = getattr(torch.nn, act)()
+    h = f(O.linear(x, sd["m.model.0.weight"], sd["m.model.0.bias"]))
+    h = f(O.linear(h, sd["m.model.2.weight"], sd["m.model.2.bias"]))
+    ref = O.layer_norm(O.linear(h, sd["m.model.4.weight"], sd["m.model.4.bias"]), sd["m.model.5.weight"], sd["m.model.5.bias"])
+    assert max_abs(y.cpu(), ref) < 2e-5
+
+
+def test_mlp_rejects_unsupported(native):
+    x = torch.zeros(4, 8, device=DEV)
+    w = [torch.zeros(300, 8, device=DEV), torch.zeros(4, 300, device=DEV)]
+    b = [torch.zeros(300, device=DEV), torch.zeros(4, device=DEV)]
+    with pytest.raises(RuntimeError, match="256"):
+        native.mlp_forward([(x, None)], w, b)
+    with pytest.raises(NotImplementedError):
+        native.mlp_forward([(x, None)], [w[0][:8], w[1][:, :8]], [b[0][:8], b[1]], activation="Softplus")
