@@ -1,0 +1,288 @@
+"""Drop-in for the reference's ``models/GNN.py``: same public names, constructors, kwargs
+defaults and ``state_dict`` layout; the forward path runs in hand-written HIP kernels
+(CSR scatter-sum K1, fused gather+concat+MLP+LayerNorm+residual K4, edge features K6).
+
+Reference: models/GNN.py:3-341.  Differences that are deliberate and documented in
+DESIGN.md: inside ``GraphNet``/``GraphProcessor`` the edge latents are kept in
+destination-sorted order (a stable sort, so every per-destination sum adds in the
+reference's edge order), and inputs given on the CPU are moved to the module's GPU and the
+result moved back, because the reference's callers (utils/train_model.py:37,
+utils/inference.py:59) never place tensors themselves.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from . import functional as Fn
+from .MLP import MLP, default_device, require_gpu_param
+from .topology import GraphTopology, get_topology
+
+
+# --------------------------------------------------------------------------- a1 scatter_sum
+def scatter_sum(src: Tensor, index: Tensor, dim: int = 0, dim_size: int | None = None) -> Tensor:
+    """Operator-level seam of the reference (models/GNN.py:4-21), same signature and errors.
+
+    ``src`` rows may be in any order; the destination CSR for ``index`` is built (or taken from
+    the topology cache) and the sum runs in the atomics-free HIP kernel.  ``dim_size=None``
+    costs a host sync exactly like the reference's ``index.max().item()``."""
+    if dim != 0:
+        raise NotImplementedError("fallback scatter_sum currently supports dim=0 only")
+    if src.ndim == 1:
+        src = src.unsqueeze(-1)
+    if dim_size is None:
+        dim_size = int(index.max().item()) + 1 if index.numel() > 0 else 0
+    dev = src.device if src.is_cuda else default_device()
+    if dev.type != "cuda":
+        raise RuntimeError("scatter_sum: no GPU visible and no CPU fallback exists")
+    out_device = src.device
+    ei = torch.stack([index.long(), index.long()])  # only the destination row is used
+    topo = get_topology(ei, dim_size, dev)
+    out = Fn.scatter_sum_csr(src.to(device=dev, dtype=torch.float32), topo.rowptr, topo.perm, topo.col32, dim_size)
+    return out if out_device == dev else out.to(out_device)
+
+
+# --------------------------------------------------------------------------- a3 EdgeProcessor
+class EdgeProcessor(nn.Module):
+    def __init__(self, in_dim_node: int, in_dim_edge: int, hidden_dim: int = 128, hidden_layers: int = 2,
+                 activation: str = "ReLU", initializer: None | str = None, norm_type: None | str = "LayerNorm"):
+        """models/GNN.py:31-55."""
+        super().__init__()
+        self.edge_processor = MLP(2 * in_dim_node + in_dim_edge, in_dim_edge, hidden_dim, hidden_layers, activation,
+                                  initializer, norm_type)
+
+    def forward(self, src, dest, edge_attr, u=None, batch=None):
+        """MetaLayer edge-model contract (models/GNN.py:57-64): MLP(cat[src, dest, e]) + e."""
+        dev = require_gpu_param(self.edge_processor.model[0].weight, "EdgeProcessor")
+        back = edge_attr.device
+        src, dest, edge_attr = (t.to(device=dev, dtype=torch.float32) for t in (src, dest, edge_attr))
+        out = self.edge_processor.forward_segments([(src, None), (dest, None), (edge_attr, None)], residual=edge_attr)
+        return out if back == dev else out.to(back)
+
+    def forward_sorted(self, x: Tensor, topo: GraphTopology, edge_attr: Tensor) -> Tensor:
+        """Same math with the two row gathers fused into the kernel; ``edge_attr`` and the
+        result are in destination-sorted edge order."""
+        return self.edge_processor.forward_segments(
+            [(x, topo.src_sorted), (x, topo.dst_sorted), (edge_attr, None)], residual=edge_attr, rows=topo.num_edges)
+
+
+# --------------------------------------------------------------------------- a2 NodeProcessor
+class NodeProcessor(nn.Module):
+    def __init__(self, in_dim_node: int, in_dim_edge: int, hidden_dim: int = 128, hidden_layers: int = 2,
+                 activation: str = "ReLU", initializer: None | str = None, norm_type: None | str = "LayerNorm"):
+        """models/GNN.py:69-93."""
+        super().__init__()
+        self.node_processor = MLP(in_dim_node + in_dim_edge, in_dim_node, hidden_dim, hidden_layers, activation,
+                                  initializer, norm_type)
+
+    def forward(self, x: Tensor, edge_index: Tensor, edge_attr: Tensor, u=None, batch=None):
+        """MetaLayer node-model contract (models/GNN.py:95-104): MLP(cat[x, scatter_sum(e, col)]) + x."""
+        dev = require_gpu_param(self.node_processor.model[0].weight, "NodeProcessor")
+        back = x.device
+        x, edge_attr = (t.to(device=dev, dtype=torch.float32) for t in (x, edge_attr))
+        topo = get_topology(edge_index, x.size(0), dev)
+        agg = Fn.scatter_sum_csr(edge_attr, topo.rowptr, topo.perm, topo.col32, topo.num_nodes)
+        out = self.node_processor.forward_segments([(x, None), (agg, None)], residual=x)
+        return out if back == dev else out.to(back)
+
+    def forward_sorted(self, x: Tensor, topo: GraphTopology, edge_attr: Tensor) -> Tensor:
+        agg = Fn.scatter_sum_csr(edge_attr, topo.rowptr, None, topo.dst_sorted, topo.num_nodes)
+        return self.node_processor.forward_segments([(x, None), (agg, None)], residual=x)
+
+
+# --------------------------------------------------------------------------- a4 MetaLayer glue
+class MetaLayer(nn.Module):
+    """The subset of ``torch_geometric.nn.MetaLayer`` the reference uses (models/GNN.py:24,
+    :146-165, :215): ``edge_model`` then ``node_model``, no global model; attribute names are
+    PyG's so ``state_dict`` keys match (``blocks.<i>.edge_model...``)."""
+
+    def __init__(self, edge_model=None, node_model=None, global_model=None):
+        super().__init__()
+        if global_model is not None:
+            raise NotImplementedError("global_model is not used by the reference and not implemented")
+        self.edge_model = edge_model
+        self.node_model = node_model
+        self.global_model = None
+
+    def forward(self, x: Tensor, edge_index: Tensor, edge_attr: Tensor | None = None, u=None, batch=None):
+        dev = require_gpu_param(next(self.parameters()), "MetaLayer")
+        back = x.device
+        x = x.to(device=dev, dtype=torch.float32)
+        edge_attr = edge_attr.to(device=dev, dtype=torch.float32)
+        topo = get_topology(edge_index, x.size(0), dev)
+        e_sorted = Fn.permute_rows(edge_attr, topo.perm, topo.inv_perm)
+        x, e_sorted = self.forward_sorted(x, topo, e_sorted)
+        edge_attr = Fn.permute_rows(e_sorted, topo.inv_perm, topo.perm)
+        if back != dev:
+            x, edge_attr = x.to(back), edge_attr.to(back)
+        return x, edge_attr, u
+
+    def forward_sorted(self, x: Tensor, topo: GraphTopology, edge_attr: Tensor):
+        if self.edge_model is not None:
+            edge_attr = self.edge_model.forward_sorted(x, topo, edge_attr)
+        if self.node_model is not None:
+            x = self.node_model.forward_sorted(x, topo, edge_attr)
+        return x, edge_attr
+
+
+def build_GN_block(in_dim_node: int, in_dim_edge: int, hidden_dim_node: int = 128, hidden_dim_edge: int = 128,
+                   hidden_layers_node: int = 2, hidden_layers_edge: int = 2, activation: str = "ReLU",
+                   initializer: None | str = None, norm_type: None | str = "LayerNorm"):
+    """models/GNN.py:110-165."""
+    return MetaLayer(
+        edge_model=EdgeProcessor(in_dim_node, in_dim_edge, hidden_dim_edge, hidden_layers_edge, activation,
+                                 initializer, norm_type),
+        node_model=NodeProcessor(in_dim_node, in_dim_edge, hidden_dim_node, hidden_layers_node, activation,
+                                 initializer, norm_type),
+    )
+
+
+# --------------------------------------------------------------------------- a6 GraphProcessor
+class GraphProcessor(nn.Module):
+    def __init__(self, n_iterations: int, in_dim_node: int, in_dim_edge: int, hidden_dim_node: int = 128,
+                 hidden_dim_edge: int = 128, hidden_layers_node: int = 2, hidden_layers_edge: int = 2,
+                 activation: str = "ReLU", initializer: None | str = None, norm_type="LayerNorm"):
+        """n_iterations GN blocks with unshared weights (models/GNN.py:168-211)."""
+        super().__init__()
+        self.blocks = nn.ModuleList()
+        for _ in range(n_iterations):
+            self.blocks.append(build_GN_block(in_dim_node, in_dim_edge, hidden_dim_node, hidden_dim_edge,
+                                              hidden_layers_node, hidden_layers_edge, activation, initializer,
+                                              norm_type))
+
+    def forward(self, x, edge_index, edge_attr):
+        """models/GNN.py:213-216; ``edge_attr`` in and out in the caller's edge order."""
+        if len(self.blocks) == 0:
+            return x, edge_attr
+        dev = require_gpu_param(next(self.parameters()), "GraphProcessor")
+        back = x.device
+        x = x.to(device=dev, dtype=torch.float32)
+        edge_attr = edge_attr.to(device=dev, dtype=torch.float32)
+        topo = get_topology(edge_index, x.size(0), dev)
+        x, e_sorted = self.forward_sorted(x, topo, Fn.permute_rows(edge_attr, topo.perm, topo.inv_perm))
+        edge_attr = Fn.permute_rows(e_sorted, topo.inv_perm, topo.perm)
+        if back != dev:
+            x, edge_attr = x.to(back), edge_attr.to(back)
+        return x, edge_attr
+
+    def forward_sorted(self, x, topo: GraphTopology, edge_attr):
+        for block in self.blocks:
+            x, edge_attr = block.forward_sorted(x, topo, edge_attr)
+        return x, edge_attr
+
+
+# --------------------------------------------------------------------------- a7 GraphNet
+class GraphNet(nn.Module):
+    def __init__(self, **kwargs):
+        """Encode-process-decode GraphNet; kwargs and defaults of models/GNN.py:223-295."""
+        super().__init__()
+        num_global_features = kwargs.get("num_global_features", 0)
+        num_local_features = kwargs.get("num_local_features", 3)
+        space_dim = kwargs.get("space_dim", 2)
+        in_dim_node = num_local_features + num_global_features
+        in_dim_edge = 1 + space_dim
+        out_dim = kwargs.get("out_channels", 1)
+        n_blocks = kwargs.get("n_blocks", 10)
+        out_dim_node = kwargs.get("out_dim_node", 128)
+        out_dim_edge = kwargs.get("out_dim_edge", 128)
+        hidden_dim_node = kwargs.get("hidden_dim_node", 128)
+        hidden_dim_edge = kwargs.get("hidden_dim_edge", 128)
+        hidden_dim_decoder = kwargs.get("hidden_dim_decoder", 128)
+        hidden_dim_processor_node = kwargs.get("hidden_dim_processor_node", 128)
+        hidden_dim_processor_edge = kwargs.get("hidden_dim_processor_edge", 128)
+        hidden_layers_node = kwargs.get("hidden_layers_node", 2)
+        hidden_layers_edge = kwargs.get("hidden_layers_edge", 2)
+        hidden_layers_decoder = kwargs.get("hidden_layers_decoder", 2)
+        hidden_layers_processor_node = kwargs.get("hidden_layers_processor_node", 2)
+        hidden_layers_processor_edge = kwargs.get("hidden_layers_processor_edge", 2)
+        norm_type = kwargs.get("norm_type", "LayerNorm")
+        activation = kwargs.get("activation", "ReLU")
+        initializer = kwargs.get("initializer", None)
+
+        self.name = "GraphNet"
+        self.out_dim = out_dim
+        self.space_dim = space_dim
+
+        self.node_encoder = MLP(in_dim_node, out_dim_node, hidden_dim_node, hidden_layers_node, activation=activation,
+                                initializer=initializer, norm_type=norm_type)
+        self.edge_encoder = MLP(in_dim_edge, out_dim_edge, hidden_dim_edge, hidden_layers_edge, activation=activation,
+                                initializer=initializer, norm_type=norm_type)
+        self.graph_processor = GraphProcessor(n_blocks, out_dim_node, out_dim_edge, hidden_dim_processor_node,
+                                              hidden_dim_processor_edge, hidden_layers_processor_node,
+                                              hidden_layers_processor_edge, activation=activation,
+                                              initializer=initializer, norm_type=norm_type)
+        self.node_decoder = MLP(out_dim_node, out_dim, hidden_dim_decoder, hidden_layers_decoder, norm_type=None)
+
+    def forward_device(self, x: Tensor, pos: Tensor, topo: GraphTopology) -> Tensor:
+        """GraphNet.forward on device tensors with a prepared topology (models/GNN.py:297-309)."""
+        edge_attr = Fn.edge_features(pos, topo.src_sorted, topo.dst_sorted)            # :299-302 (K6)
+        out = self.node_encoder.forward_segments([(x.view(x.size(0), -1), None)])         # :305
+        edge_attr = self.edge_encoder.forward_segments([(edge_attr, None)])               # :306
+        out, _ = self.graph_processor.forward_sorted(out, topo, edge_attr)                # :307
+        return self.node_decoder.forward_segments([(out, None)])                          # :308
+
+    def forward(self, x, pos, edge_index):
+        dev = require_gpu_param(self.node_encoder.model[0].weight, "GraphNet")
+        back = x.device
+        x = x.to(device=dev, dtype=torch.float32)
+        pos = pos.to(device=dev, dtype=torch.float32)
+        topo = get_topology(edge_index, x.size(0), dev)
+        out = self.forward_device(x, pos, topo)
+        return out if back == dev else out.to(back)
+
+
+# --------------------------------------------------------------------------- a8 read-out
+class LinearClassifier(nn.Module):
+    def __init__(self, in_features=128 * 128, classes=2):
+        """models/GNN.py:312-325; three small dense layers left to PyTorch-ROCm."""
+        super().__init__()
+        self.fc1 = nn.Linear(in_features=in_features, out_features=128)
+        self.fc2 = nn.Linear(in_features=128, out_features=32)
+        self.fc3 = nn.Linear(in_features=32, out_features=classes)
+        self.relu = nn.ReLU()
+
+    def forward(self, x):
+        x = self.relu(self.fc1(x))
+        x = self.relu(self.fc2(x))
+        return self.fc3(x)
+
+
+class CombinedModel(nn.Module):
+    def __init__(self, graph_net: GraphNet | None = None, num_nodes: int = 128 * 128, classes: int = 2):
+        """models/GNN.py:327-332."""
+        super().__init__()
+        self.graph_net = graph_net if graph_net is not None else GraphNet()
+        self.num_nodes = num_nodes
+        in_features = num_nodes * self.graph_net.out_dim
+        self.classifier = LinearClassifier(in_features=in_features, classes=classes)
+        self.to(next(self.graph_net.parameters()).device)
+
+    def forward(self, x, pos=None, edge_index=None):
+        """models/GNN.py:334-341; accepts the (x, pos, edge_index) tuple; logits are 1-D [classes]."""
+        if pos is None and edge_index is None and isinstance(x, tuple):
+            x, pos, edge_index = x
+        dev = require_gpu_param(self.classifier.fc1.weight, "CombinedModel")
+        back = x.device
+        x = x.to(device=dev, dtype=torch.float32)
+        pos = pos.to(device=dev, dtype=torch.float32)
+        topo = get_topology(edge_index, x.size(0), dev)
+        y = self.graph_net.forward_device(x, pos, topo).flatten()
+        logits = self.classifier(y)
+        return logits if back == dev else logits.to(back)
+
+    def forward_batched(self, x, pos, edge_index, num_graphs: int):
+        """Block-diagonal batch of ``num_graphs`` graphs of exactly ``num_nodes`` nodes each
+        (graph g owns node rows g*num_nodes ...): one GraphNet pass, then the read-out as a
+        [G, num_nodes*out_dim] GEMM.  Equals ``num_graphs`` independent ``forward`` calls; the
+        reference has no batching (main.py:60)."""
+        dev = require_gpu_param(self.classifier.fc1.weight, "CombinedModel")
+        back = x.device
+        if x.size(0) != num_graphs * self.num_nodes:
+            raise ValueError(f"expected {num_graphs} x {self.num_nodes} node rows, got {x.size(0)}")
+        x = x.to(device=dev, dtype=torch.float32)
+        pos = pos.to(device=dev, dtype=torch.float32)
+        topo = get_topology(edge_index, x.size(0), dev)
+        y = self.graph_net.forward_device(x, pos, topo).view(num_graphs, -1)
+        logits = self.classifier(y)
+        return logits if back == dev else logits.to(back)

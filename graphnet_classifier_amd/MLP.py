@@ -1,0 +1,99 @@
+"""Drop-in for the reference's ``models/MLP.py``: same constructor, same ``state_dict``
+keys (``model.<i>.weight`` ...), forward executed by the fused HIP kernel K4.
+
+Reference: models/MLP.py:5-47.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from . import functional as Fn
+from . import native
+
+
+def default_device() -> torch.device:
+    """Device new modules are created on: the current ROCm device when one is visible (the
+    reference never calls ``.to(device)``, so a drop-in has to place itself), else CPU -- on
+    which only construction and state-dict handling work, never ``forward``."""
+    if torch.cuda.is_available():
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def require_gpu_param(p: Tensor, what: str) -> torch.device:
+    if not p.is_cuda:
+        raise RuntimeError(
+            f"{what}: parameters are on {p.device}; the forward path exists only as HIP kernels for the MI355X "
+            f"(no CPU fallback).  Construct the module on a machine with a visible GPU or call .to('cuda').")
+    return p.device
+
+
+class MLP(nn.Module):
+    def __init__(
+        self,
+        in_dim: int,
+        out_dim: int,
+        hidden_dim: int = 128,
+        hidden_layers: int = 2,
+        activation: str = "ReLU",
+        initializer: None | str = None,
+        norm_type: None | str = "LayerNorm",
+    ):
+        """Linear/act x hidden_layers, Linear, optional norm (models/MLP.py:24-37)."""
+        super().__init__()
+        self.activation = getattr(nn, activation)()
+        self.activation_name = activation
+        if initializer is not None:
+            self.initializer = getattr(nn.init, initializer)
+        layers = [nn.Linear(in_dim, hidden_dim), self.activation]
+        for _ in range(hidden_layers - 1):
+            layers += [nn.Linear(hidden_dim, hidden_dim), self.activation]
+        layers.append(nn.Linear(hidden_dim, out_dim))
+        if norm_type is not None:
+            assert norm_type in ["LayerNorm", "BatchNorm1d"]  # models/MLP.py:30-33
+            layers.append(getattr(nn, norm_type)(out_dim))
+        self.norm_type = norm_type
+        self.model = nn.Sequential(*layers)
+        if initializer is not None:
+            for param in self.model.parameters():
+                if param.requires_grad and len(param.shape) > 1:
+                    self.initializer(param)
+        self.to(default_device())
+
+    # -- pieces of the Sequential the kernel consumes ------------------------------------
+    def _linears(self):
+        return [m for m in self.model if isinstance(m, nn.Linear)]
+
+    def _act_param(self) -> float:
+        a = self.activation
+        return float(getattr(a, "negative_slope", getattr(a, "alpha", 0.0)))
+
+    def forward_segments(self, segments, residual: Tensor | None = None, rows: int | None = None) -> Tensor:
+        """Run the MLP on the virtual concat of ``segments`` = [(table, int32 index | None)]
+        (device tensors), optionally adding ``residual``: concat, gathers, Linear chain,
+        LayerNorm and residual are one kernel launch."""
+        lin = self._linears()
+        require_gpu_param(lin[0].weight, "MLP")
+        if self.activation_name not in native.ACTIVATIONS:
+            raise NotImplementedError(f"activation nn.{self.activation_name} has no HIP kernel "
+                                      f"(available: {sorted(native.ACTIVATIONS)})")
+        norm = self.model[-1] if self.norm_type is not None else None
+        ln = (norm.weight, norm.bias, norm.eps) if isinstance(norm, nn.LayerNorm) else None
+        fuse_res = residual if not isinstance(norm, nn.BatchNorm1d) else None
+        y = Fn.fused_mlp(segments, [m.weight for m in lin], [m.bias for m in lin], ln=ln,
+                         activation=self.activation_name, act_param=self._act_param(), residual=fuse_res, rows=rows)
+        if isinstance(norm, nn.BatchNorm1d):  # batch statistics span all rows: PyTorch-ROCm op on the GPU
+            y = norm(y)
+            if residual is not None:
+                y = y + residual
+        return y
+
+    def forward(self, x: Tensor):
+        """models/MLP.py:45-47: flatten to (rows, -1), cast to float32, run the Sequential."""
+        dev = require_gpu_param(self.model[0].weight, "MLP")
+        src_device = x.device
+        x = x.view(x.size(0), -1).to(device=dev, dtype=torch.float32)
+        y = self.forward_segments([(x, None)])
+        return y if src_device == dev else y.to(src_device)

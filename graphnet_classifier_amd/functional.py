@@ -1,0 +1,136 @@
+"""Autograd-aware operators over the HIP kernels.
+
+Forward passes run in ``libgnc_hip.so`` (see :mod:`graphnet_classifier_amd.native`).  The
+reference's only caller that needs gradients is ``utils/train_model.py:41``
+(``loss.backward()``):
+
+* scatter-sum backward is a row gather (HIP kernel K2);
+* the fused-MLP backward recomputes the small MLP with PyTorch-ROCm GPU ops and
+  differentiates that (SURVEY.md section 8 f3 lists hand-written backward kernels as the next
+  row; nothing here ever runs on the CPU).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from . import native
+
+
+class _ScatterSumCSR(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, rowptr, perm, dst_of_row, num_nodes):
+        ctx.save_for_backward(dst_of_row)
+        return native.scatter_sum_csr(src, rowptr, perm, num_nodes)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (dst_of_row,) = ctx.saved_tensors  # d out[dst(e)] / d src[e] = I
+        return native.gather_rows(grad_out.contiguous(), dst_of_row), None, None, None, None
+
+
+def scatter_sum_csr(src: torch.Tensor, rowptr: torch.Tensor, perm, dst_of_row: torch.Tensor, num_nodes: int):
+    """out[v] = sum of src rows whose destination is v.  ``perm`` maps sorted position ->
+    row of ``src`` (None when ``src`` is already destination-sorted); ``dst_of_row[r]`` is the
+    destination of ``src`` row r (int32), used by the backward gather."""
+    return _ScatterSumCSR.apply(src, rowptr, perm, dst_of_row, num_nodes)
+
+
+class _PermuteRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, table, perm, inv_perm):
+        ctx.save_for_backward(inv_perm)
+        return native.gather_rows(table, perm)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (inv_perm,) = ctx.saved_tensors
+        return native.gather_rows(grad_out.contiguous(), inv_perm), None, None
+
+
+def permute_rows(table: torch.Tensor, perm: torch.Tensor, inv_perm: torch.Tensor) -> torch.Tensor:
+    """out[k] = table[perm[k]] for a permutation ``perm`` (int32) with inverse ``inv_perm``."""
+    return _PermuteRows.apply(table, perm, inv_perm)
+
+
+def _torch_activation(name: str, param: float):
+    if name == "LeakyReLU":
+        return lambda v: F.leaky_relu(v, param)
+    if name == "ELU":
+        return lambda v: F.elu(v, param)
+    return {"ReLU": F.relu, "Identity": lambda v: v, "Tanh": torch.tanh, "Sigmoid": torch.sigmoid, "SiLU": F.silu,
+            "GELU": F.gelu}[name]
+
+
+class _MlpMeta:
+    """Non-tensor arguments of one fused-MLP call."""
+    __slots__ = ("indices", "num_linear", "activation", "act_param", "ln_eps", "has_ln", "has_residual", "rows")
+
+    def __init__(self, indices, num_linear, activation, act_param, ln_eps, has_ln, has_residual, rows):
+        self.indices, self.num_linear, self.activation, self.act_param = indices, num_linear, activation, act_param
+        self.ln_eps, self.has_ln, self.has_residual, self.rows = ln_eps, has_ln, has_residual, rows
+
+
+class _FusedMLP(torch.autograd.Function):
+    """args = tables[S] + weights[L] + biases[L] + (gamma, beta if LN) + (residual if any)."""
+
+    @staticmethod
+    def forward(ctx, meta: _MlpMeta, *args):
+        s, l = len(meta.indices), meta.num_linear
+        tables, weights, biases = args[:s], args[s:s + l], args[s + l:s + 2 * l]
+        rest = list(args[s + 2 * l:])
+        ln = (rest.pop(0), rest.pop(0), meta.ln_eps) if meta.has_ln else None
+        residual = rest.pop(0) if meta.has_residual else None
+        out = native.mlp_forward(list(zip(tables, meta.indices)), list(weights), list(biases), ln=ln,
+                                 activation=meta.activation, act_param=meta.act_param, residual=residual, rows=meta.rows)
+        ctx.meta = meta
+        ctx.save_for_backward(*args)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        meta, args = ctx.meta, ctx.saved_tensors
+        s, l = len(meta.indices), meta.num_linear
+        need = ctx.needs_input_grad[1:]
+        leaves = [a.detach().requires_grad_(bool(n)) for a, n in zip(args, need)]
+        tables, weights, biases = leaves[:s], leaves[s:s + l], leaves[s + l:s + 2 * l]
+        rest = leaves[s + 2 * l:]
+        act = _torch_activation(meta.activation, meta.act_param)
+        with torch.enable_grad():
+            h = torch.cat([t if i is None else t[i.long()] for t, i in zip(tables, meta.indices)], dim=-1)
+            for k in range(l):
+                h = F.linear(h, weights[k], biases[k])
+                if k + 1 < l:
+                    h = act(h)
+            if meta.has_ln:
+                h = F.layer_norm(h, (h.size(-1),), rest[0], rest[1], meta.ln_eps)
+            if meta.has_residual:
+                h = h + rest[-1]
+            wanted = [x for x, n in zip(leaves, need) if n]
+            grads = iter(torch.autograd.grad(h, wanted, grad_out.contiguous(), allow_unused=True))
+        return (None,) + tuple(next(grads) if n else None for n in need)
+
+
+def fused_mlp(segments, weights, biases, ln=None, activation: str = "ReLU", act_param: float = 0.0, residual=None,
+              rows: int | None = None) -> torch.Tensor:
+    """segments: list of (table fp32 [*, w], index int32 [rows] | None); see native.mlp_forward."""
+    tables = [t for t, _ in segments]
+    indices = tuple(i for _, i in segments)
+    if rows is None:
+        rows = indices[0].numel() if indices[0] is not None else tables[0].size(0)
+    meta = _MlpMeta(indices, len(weights), activation, float(act_param), float(ln[2]) if ln is not None else 0.0,
+                    ln is not None, residual is not None, int(rows))
+    args = list(tables) + list(weights) + list(biases)
+    if ln is not None:
+        args += [ln[0], ln[1]]
+    if residual is not None:
+        args.append(residual)
+    return _FusedMLP.apply(meta, *args)
+
+
+def edge_features(pos: torch.Tensor, src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    """[pos[dst]-pos[src], L1 norm] per edge (models/GNN.py:299-302).  ``pos`` is input data
+    (utils/dataloader.py:50); gradients with respect to it are not provided."""
+    if pos.requires_grad and torch.is_grad_enabled():
+        raise NotImplementedError("gradients with respect to node positions are not implemented")
+    return native.edge_features(pos, src, dst)

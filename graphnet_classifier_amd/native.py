@@ -119,6 +119,48 @@ def _ld(t: torch.Tensor) -> int:
     return t.stride(0) if t.size(0) > 1 else max(t.size(1), 1)
 
 
+# --------------------------------------------------------------------------- kernel timers
+class KernelTimers:
+    """Optional HIP-event timing of individual launches (bench.py uses it for the roofline
+    object).  Events are recorded on the stream the kernel is launched on (torch's current
+    stream); nothing is synchronised until ``summary()`` is called after the timed region."""
+
+    def __init__(self):
+        self.events = {}
+        self.work = {}
+
+    def launch(self, name: str, stream_tensor: torch.Tensor, fn, work: float = 0.0):
+        start = torch.cuda.Event(enable_timing=True)
+        end = torch.cuda.Event(enable_timing=True)
+        start.record(torch.cuda.current_stream(stream_tensor.device))
+        rc = fn()
+        end.record(torch.cuda.current_stream(stream_tensor.device))
+        self.events.setdefault(name, []).append((start, end))
+        self.work.setdefault(name, []).append(work)
+        return rc
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, evs in self.events.items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            out[name] = {"launches": len(ms), "avg_ms": sum(ms) / len(ms), "min_ms": min(ms),
+                         "avg_work": sum(self.work[name]) / len(ms)}
+        return out
+
+
+_timers: KernelTimers | None = None
+
+
+def set_kernel_timers(timers: KernelTimers | None) -> None:
+    global _timers
+    _timers = timers
+
+
+def _launch(name: str, t: torch.Tensor, fn, work: float = 0.0):
+    return _timers.launch(name, t, fn, work) if _timers is not None else fn()
+
+
 # --------------------------------------------------------------------------- topology
 def csr_build(index: torch.Tensor, num_nodes: int):
     """index [E] int64 (device) -> (rowptr int32 [N+1], perm int32 [E], status int32 [1])."""
@@ -163,10 +205,15 @@ def scatter_sum_csr(src: torch.Tensor, rowptr: torch.Tensor, perm: torch.Tensor 
     e, d = src.shape
     if out is None:
         out = torch.empty(num_nodes, d, dtype=torch.float32, device=src.device)
+    # algorithmic bytes of this launch: messages once, output once, row pointers,
+    # and one int32 per edge only when the kernel has to go through the permutation
+    work = 4.0 * d * e + 4.0 * d * num_nodes + 4.0 * (num_nodes + 1) + (4.0 * e if perm is not None else 0.0)
     with torch.cuda.device(src.device):
-        _check(lib.gnc_scatter_sum_csr_f32(src.data_ptr(), _ld(src), rowptr.data_ptr(),
-                                           perm.data_ptr() if perm is not None else None, num_nodes, e, d,
-                                           out.data_ptr(), _ld(out), _stream(src)), "gnc_scatter_sum_csr_f32")
+        _check(_launch("scatter_sum_csr" + ("_perm" if perm is not None else "_sorted"), src,
+                       lambda: lib.gnc_scatter_sum_csr_f32(src.data_ptr(), _ld(src), rowptr.data_ptr(),
+                                                           perm.data_ptr() if perm is not None else None, num_nodes,
+                                                           e, d, out.data_ptr(), _ld(out), _stream(src)), work),
+               "gnc_scatter_sum_csr_f32")
     return out
 
 
@@ -248,6 +295,10 @@ def mlp_forward(segments, weights, biases, ln=None, activation: str = "ReLU", ac
     if residual is not None:
         residual = _rowmajor(residual)
     desc = make_mlp_desc(segs, weights, biases, ln, activation, act_param, residual, out, rows)
+    # executed FLOPs of this launch: 2 * rows * sum(in*out) over the Linear layers
+    flops = 2.0 * rows * sum(w.size(0) * w.size(1) for w in weights)
     with torch.cuda.device(dev):
-        _check(lib.gnc_mlp_forward_f32(ctypes.byref(desc), _stream(out)), "gnc_mlp_forward_f32")
+        _check(_launch(f"mlp_fused_in{weights[0].size(1)}_h{weights[0].size(0)}_out{weights[-1].size(0)}", out,
+                       lambda: lib.gnc_mlp_forward_f32(ctypes.byref(desc), _stream(out)), flops),
+               "gnc_mlp_forward_f32")
     return out

@@ -1,0 +1,121 @@
+"""Graph topology for the HIP message-passing path: destination-sorted CSR, built once per
+``edge_index`` and cached.
+
+The reference re-derives the aggregation pattern inside every ``index_add_``
+(models/GNN.py:18-20) and gathers ``x[row]``, ``x[col]`` through int64 indices on every GN
+block (PyG MetaLayer, called at models/GNN.py:215).  Here ``edge_index`` is converted once:
+
+* ``rowptr`` int32 [N+1], ``perm`` int32 [E]  -- stable sort of the edges by destination
+  (``perm[k]`` = original edge id at sorted position ``k``);
+* ``src_sorted`` / ``dst_sorted`` int32 [E]    -- endpoints of the edge at sorted position k;
+* ``row32`` / ``col32`` int32 [E]               -- endpoints in ORIGINAL edge order (for the
+  operator-level API and its backward).
+
+The pixel/patch builders reuse one topology per image size (reference
+utils/image_to_graph/image_to_graph_optimized.py:42-47 caches it with lru_cache); the cache
+below does the same by content hash for host tensors and by identity for device tensors.
+"""
+from __future__ import annotations
+
+import hashlib
+from collections import OrderedDict
+
+import torch
+
+from . import native
+
+
+class GraphTopology:
+    """Device-resident CSR view of one ``edge_index`` [2, E] (int64) over ``num_nodes`` nodes."""
+
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int, device=None, validate: bool = True):
+        if edge_index.dim() != 2 or edge_index.size(0) != 2:
+            raise ValueError(f"edge_index must be [2, E], got {tuple(edge_index.shape)}")
+        device = torch.device(device) if device is not None else edge_index.device
+        if device.type != "cuda":
+            raise RuntimeError("GraphTopology lives on the GPU: pass device='cuda' (no CPU fallback exists)")
+        ei = edge_index.to(device=device, dtype=torch.int64, non_blocking=True)
+        self.num_nodes = int(num_nodes)
+        self.num_edges = int(ei.size(1))
+        self.device = device
+        row, col = ei[0].contiguous(), ei[1].contiguous()
+        self.rowptr, self.perm, status = native.csr_build(col, self.num_nodes)
+        self.src_sorted = native.permute_index(row, self.perm)
+        self.dst_sorted = native.permute_index(col, self.perm)
+        self.row32 = native.permute_index(row, None)
+        self.col32 = native.permute_index(col, None)
+        self._inv_perm = None
+        self._csc = None
+        if validate:
+            # one host sync per topology build; the reference syncs on every scatter
+            # (models/GNN.py:16-17 `index.max().item()`) and raises IndexError for a bad index
+            bad_dst = int(status.item())
+            bad_src = bool(((row < 0) | (row >= self.num_nodes)).any().item()) if self.num_edges else False
+            if bad_dst or bad_src:
+                raise IndexError(f"edge_index has node ids outside [0, {self.num_nodes})")
+
+    @property
+    def inv_perm(self) -> torch.Tensor:
+        """int32 [E]: sorted position of original edge e (inverse of ``perm``)."""
+        if self._inv_perm is None:
+            inv = torch.empty_like(self.perm)
+            inv[self.perm.long()] = torch.arange(self.num_edges, dtype=torch.int32, device=self.device)
+            self._inv_perm = inv
+        return self._inv_perm
+
+    @property
+    def csc(self):
+        """(rowptr, perm) of the SOURCE-sorted order, in sorted-edge numbering: used by the
+        backward of the fused gather (grad wrt x[src]) -- built on first use."""
+        if self._csc is None:
+            rp, pm, _ = native.csr_build(self.src_sorted.long(), self.num_nodes)
+            self._csc = (rp, pm)
+        return self._csc
+
+
+class TopologyCache:
+    """Small LRU of topologies.  Host tensors are keyed by content (shape + blake2 digest of the
+    bytes: a 32x32 pixel grid is 32 KB), device tensors by identity and version; a cached
+    device entry keeps its ``edge_index`` alive so the address cannot be recycled under it."""
+
+    def __init__(self, capacity: int = 16):
+        self.capacity = capacity
+        self._entries: OrderedDict = OrderedDict()
+        self.hits = 0
+        self.misses = 0
+
+    @staticmethod
+    def _key(edge_index: torch.Tensor, num_nodes: int, device):
+        if edge_index.is_cuda:
+            return ("dev", edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), num_nodes, str(device))
+        buf = edge_index.contiguous().numpy().tobytes()
+        return ("host", hashlib.blake2b(buf, digest_size=16).digest(), tuple(edge_index.shape), str(edge_index.dtype),
+                num_nodes, str(device))
+
+    def get(self, edge_index: torch.Tensor, num_nodes: int, device) -> GraphTopology:
+        key = self._key(edge_index, num_nodes, device)
+        hit = self._entries.get(key)
+        if hit is not None:
+            self._entries.move_to_end(key)
+            self.hits += 1
+            return hit[0]
+        self.misses += 1
+        topo = GraphTopology(edge_index, num_nodes, device=device)
+        self._entries[key] = (topo, edge_index if edge_index.is_cuda else None)
+        while len(self._entries) > self.capacity:
+            self._entries.popitem(last=False)
+        return topo
+
+    def clear(self):
+        self._entries.clear()
+
+
+_default_cache = TopologyCache()
+
+
+def get_topology(edge_index: torch.Tensor, num_nodes: int, device) -> GraphTopology:
+    return _default_cache.get(edge_index, num_nodes, device)
+
+
+def clear_topology_cache():
+    _default_cache.clear()

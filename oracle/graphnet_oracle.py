@@ -123,10 +123,29 @@ def edge_processor(sd: dict, prefix: str, src: Tensor, dest: Tensor, edge_attr: 
     return out + edge_attr
 
 
+def scatter_sum_index_add(src: Tensor, index: Tensor, dim_size: int) -> Tensor:
+    """Literally the reference's fallback body (models/GNN.py:18-20): zero-init + ATen
+    ``index_add_``.  Used when the oracle is TIMED as the CPU baseline (bench.py), so that the
+    baseline runs the same multi-threaded ATen kernel the reference runs; checked equal to the
+    edge-ordered loop in tests/test_oracle_golden.py."""
+    out = src.new_zeros((dim_size, src.size(1)))
+    out.index_add_(0, index.long(), src)
+    return out
+
+
+SCATTER_IMPL = {"sorted_loop": scatter_sum_fast, "index_add": scatter_sum_index_add}
+_scatter = scatter_sum_fast
+
+
+def set_scatter_impl(name: str) -> None:
+    global _scatter
+    _scatter = SCATTER_IMPL[name]
+
+
 def node_processor(sd: dict, prefix: str, x: Tensor, edge_index: Tensor, edge_attr: Tensor) -> Tensor:
     """models/GNN.py:95-104: MLP(cat[x, scatter_sum(e, col)]) + x."""
     col = edge_index[1]
-    agg = scatter_sum_fast(edge_attr, col, x.size(0))
+    agg = _scatter(edge_attr, col, x.size(0))
     out = torch.cat([x, agg], dim=-1)
     out = mlp_forward(sd, prefix + ".node_processor", out)
     return out + x

@@ -30,6 +30,19 @@ def test_g1_scatter_sum():
     assert tuple(O.scatter_sum(torch.zeros(0, 8), torch.zeros(0, dtype=torch.long)).shape) == tuple(g["out_empty_shape"])
     with pytest.raises(NotImplementedError):
         O.scatter_sum(src, index, dim=1)
+    assert max_abs(O.scatter_sum_index_add(src, index, 37), t(g["out_infer"])) < TOL
+
+
+def test_g1_c_oracle():
+    from oracle import c_oracle
+    g = load_golden("g1_scatter.npz")
+    assert np.array_equal(c_oracle.scatter_sum(g["src"], g["index"], 37), g["out_infer"])
+    assert np.array_equal(c_oracle.scatter_sum(g["src"], g["index"], 40), g["out_dimsize40"])
+    rowptr, perm = c_oracle.csr_build(g["index"], 37)
+    assert np.array_equal(perm, np.argsort(g["index"], kind="stable").astype(np.int32))
+    assert np.array_equal(np.diff(rowptr), np.bincount(g["index"], minlength=37))
+    with pytest.raises(IndexError):
+        c_oracle.scatter_sum(g["src"], g["index"], 5)
 
 
 @pytest.mark.parametrize("tag", [f"{n}_hl{h}" for n in ("ln", "nonorm") for h in (1, 2, 3)])

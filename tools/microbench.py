@@ -7,10 +7,14 @@ import argparse
 import json
 import time
 
+import os
+import sys
+
 import numpy as np
 import torch
 
-from graphnet_classifier_amd import native
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from graphnet_classifier_amd import native  # noqa: E402
 
 
 def timeit(fn, iters, warmup=3):
