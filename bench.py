@@ -38,12 +38,36 @@ HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 MFMA peak
 
 
+def usable_cpus() -> int:
+    """Host cores this process may really use: the affinity mask, capped by the cgroup CPU quota
+    (a GPU box hands a 1-GPU job a share of the host, not all of its hardware threads)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                quota = int(parts[0])
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    period = int(f.read())
+                if quota > 0:
+                    n = min(n, max(1, quota // period))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    env = os.environ.get("GNC_CPU_THREADS")
+    return int(env) if env else min(n, 16)  # 16 = the documented CPU share of a 1-GPU box
+
+
 def cpu_baseline(batch, kw, n_blocks, target_seconds=12.0):
     """Times the CPU oracle (kind 'port': the repo's restatement of the reference forward, using
     the reference's own index_add_ scatter) on a bounded sample of the same workload."""
     from oracle import graphnet_oracle as O
     O.set_scatter_impl("index_add")
-    threads = os.cpu_count() or 1
+    threads = usable_cpus()
     torch.set_num_threads(threads)
     torch.manual_seed(0)
     ref_model = GraphNet(**kw)  # same seed -> same weights as the GPU model

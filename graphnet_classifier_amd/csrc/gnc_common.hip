@@ -19,5 +19,5 @@ extern "C" {
 int gnc_abi_version(void) { return GNC_ABI_VERSION; }
 const char* gnc_last_error_string(void) { return gnc::g_err; }
 const char* gnc_target_arch(void) { return "gfx950"; }
-size_t gnc_sizeof_mlp_desc(void) { return sizeof(gnc_mlp_desc_t); }
+
 }

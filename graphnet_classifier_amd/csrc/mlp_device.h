@@ -1,0 +1,263 @@
+// Device-side helpers shared by the fused-MLP kernels (mlp_fused.hip: weights streamed through
+// LDS; mlp_resident.hip: weights resident in LDS).  The formulation is described at the top of
+// mlp_fused.hip.
+#pragma once
+#include "gnc_common.h"
+
+namespace gnc_mlp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int KC = 64;    // k-chunk: columns of one staged weight / activation block
+constexpr int LDSW = 68;  // padded LDS row in floats (4 * odd): conflict-free ds_read_b128 fragments
+constexpr int RPW = 32;   // data rows per wave (the N dimension of the 32x32 MFMA tile)
+
+__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ void wave_lds_fence() {
+  // LDS traffic of one wave is processed in issue order; this only stops the compiler from
+  // moving LDS accesses across the point and waits for outstanding LDS returns.
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+__device__ __forceinline__ float activate(float x, int act, float p) {
+  switch (act) {
+    case GNC_ACT_RELU: return x < 0.f ? 0.f : x;  // NaN propagates like torch.clamp_min
+    case GNC_ACT_IDENTITY: return x;
+    case GNC_ACT_TANH: return tanhf(x);
+    case GNC_ACT_SIGMOID: return 1.f / (1.f + expf(-x));
+    case GNC_ACT_SILU: return x / (1.f + expf(-x));
+    case GNC_ACT_GELU: return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
+    case GNC_ACT_LEAKY_RELU: return x < 0.f ? x * p : x;
+    case GNC_ACT_ELU: return x > 0.f ? x : p * (expf(x) - 1.f);
+    default: return x;
+  }
+}
+
+template <int T>
+__device__ __forceinline__ void activate_tiles(f32x16 (&acc)[T], int act, float p) {
+  if (act == GNC_ACT_RELU) {  // hot case kept branch-free
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = acc[t][r] < 0.f ? 0.f : acc[t][r];
+  } else {
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = activate(acc[t][r], act, p);
+  }
+}
+
+// feature index held by accumulator register r of tile t on lane half h
+__device__ __forceinline__ constexpr int feat_of(int t, int r, int h) { return 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// 4 floats at p[0..3], elements at column >= limit read as 0; vector load when allowed.
+__device__ __forceinline__ f32x4 load4_guarded(const float* p, int col, int limit, bool vec_ok) {
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (vec_ok && col + 4 <= limit) {
+    v = *reinterpret_cast<const f32x4*>(p);
+  } else {
+    if (col + 0 < limit) v.x = p[0];
+    if (col + 1 < limit) v.y = p[1];
+    if (col + 2 < limit) v.z = p[2];
+    if (col + 3 < limit) v.w = p[3];
+  }
+  return v;
+}
+
+// Workgroup-wide: wbuf[n][0 .. ncol4*4) = W[n][kbase + ..] for n < TROWS, zero outside the
+// matrix.  16 lanes cover one 64-float row, so a pass of NT threads covers NT/16 weight rows.
+template <int TROWS, int NT>
+__device__ __forceinline__ void stage_weights(float* wbuf, const float* __restrict__ W, int ldw, int out_dim,
+                                              int kbase, int klimit, int ncol4, bool vec_ok, int tid) {
+  constexpr int RPP = NT / 16;
+  static_assert(TROWS % RPP == 0, "weight rows must be a multiple of the rows staged per pass");
+  const int c4 = tid & 15;
+  const int r0 = tid >> 4;
+  if (c4 < ncol4) {
+#pragma unroll
+    for (int p = 0; p < TROWS / RPP; ++p) {
+      const int n = p * RPP + r0;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (n < out_dim) v = load4_guarded(W + (int64_t)n * ldw + kbase + c4 * 4, kbase + c4 * 4, klimit, vec_ok);
+      *reinterpret_cast<f32x4*>(wbuf + n * LDSW + c4 * 4) = v;
+    }
+  }
+}
+
+// biases, LayerNorm gamma and beta, zero padded to PSTRIDE floats per row, into LDS
+template <int NT>
+__device__ __forceinline__ void stage_params(float* pbuf, const gnc_mlp_desc_t& d, int pstride, int tid) {
+  const int L = d.num_linear;
+  const int out_dim = d.out_dim[L - 1];
+  for (int idx = tid; idx < (L + 2) * pstride; idx += NT) {
+    const int l = idx / pstride, n = idx - l * pstride;
+    float v = 0.f;
+    if (l < L) {
+      if (d.bias[l] && n < d.out_dim[l]) v = d.bias[l][n];
+    } else if (d.ln_gamma && n < out_dim) {
+      v = (l == L) ? d.ln_gamma[n] : (d.ln_beta ? d.ln_beta[n] : 0.f);
+    }
+    pbuf[idx] = v;
+  }
+}
+
+template <int T>
+__device__ __forceinline__ void init_bias(f32x16 (&acc)[T], const float* pb, int h) {
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(pb + 32 * t + 8 * q + 4 * h);
+      acc[t][4 * q + 0] = b.x; acc[t][4 * q + 1] = b.y; acc[t][4 * q + 2] = b.z; acc[t][4 * q + 3] = b.w;
+    }
+}
+
+// acc[t] += W_chunk[32t + i][8g + 4h + s] * X[i][8g + 4h + s] for g < kc8: one staged 64-column
+// chunk of the first Linear; A fragments from wbuf, B fragments from the wave's row tile.
+template <int T>
+__device__ __forceinline__ void mma_chunk_from_lds(f32x16 (&acc)[T], const float* abuf, const float* wbuf, int kc8,
+                                                   int i, int h) {
+#pragma unroll 2
+  for (int g = 0; g < kc8; ++g) {
+    const f32x4 b = *reinterpret_cast<const f32x4*>(abuf + i * LDSW + 8 * g + 4 * h);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(wbuf + (32 * t + i) * LDSW + 8 * g + 4 * h);
+      acc[t] = mfma(a.x, b.x, acc[t]);
+      acc[t] = mfma(a.y, b.y, acc[t]);
+      acc[t] = mfma(a.z, b.z, acc[t]);
+      acc[t] = mfma(a.w, b.w, acc[t]);
+    }
+  }
+}
+
+// dst[t] += W_chunk * src for the 64-column chunk `c` of a Linear whose input is the previous
+// layer's accumulators (register r of tile ts holds feature 32*ts + 8*(r>>2) + 4h + (r&3)).
+template <int TI, int TO>
+__device__ __forceinline__ void mma_chunk_from_regs(f32x16 (&dst)[TO], const f32x16 (&src)[TI], const float* wbuf,
+                                                    int c, int in_dim, int i, int h) {
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    const int ts = 2 * c + (g >> 2);
+    if (ts < TI && c * KC + g * 8 < in_dim) {
+      const int q = g & 3;
+#pragma unroll
+      for (int t = 0; t < TO; ++t) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(wbuf + (32 * t + i) * LDSW + 8 * g + 4 * h);
+        dst[t] = mfma(a.x, src[ts < TI ? ts : 0][4 * q + 0], dst[t]);
+        dst[t] = mfma(a.y, src[ts < TI ? ts : 0][4 * q + 1], dst[t]);
+        dst[t] = mfma(a.z, src[ts < TI ? ts : 0][4 * q + 2], dst[t]);
+        dst[t] = mfma(a.w, src[ts < TI ? ts : 0][4 * q + 3], dst[t]);
+      }
+    }
+  }
+}
+
+// LayerNorm over the out_dim features of each data row: registers + one cross-half exchange.
+template <int OT>
+__device__ __forceinline__ void layer_norm_tiles(f32x16 (&o)[OT], const float* pg, const float* pbt, int out_dim,
+                                                 float eps, int h) {
+  float s = 0.f;
+#pragma unroll
+  for (int t = 0; t < OT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += (feat_of(t, r, h) < out_dim) ? o[t][r] : 0.f;
+  s += __shfl_xor(s, 32, 64);
+  const float mean = s / (float)out_dim;
+  float v = 0.f;
+#pragma unroll
+  for (int t = 0; t < OT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float dlt = o[t][r] - mean;
+      v += (feat_of(t, r, h) < out_dim) ? dlt * dlt : 0.f;
+    }
+  v += __shfl_xor(v, 32, 64);
+  const float rstd = 1.f / sqrtf(v / (float)out_dim + eps);
+#pragma unroll
+  for (int t = 0; t < OT; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(pg + 32 * t + 8 * q + 4 * h);
+      const f32x4 bt = *reinterpret_cast<const f32x4*>(pbt + 32 * t + 8 * q + 4 * h);
+      o[t][4 * q + 0] = (o[t][4 * q + 0] - mean) * rstd * gm.x + bt.x;
+      o[t][4 * q + 1] = (o[t][4 * q + 1] - mean) * rstd * gm.y + bt.y;
+      o[t][4 * q + 2] = (o[t][4 * q + 2] - mean) * rstd * gm.z + bt.z;
+      o[t][4 * q + 3] = (o[t][4 * q + 3] - mean) * rstd * gm.w + bt.w;
+    }
+}
+
+// Epilogue: transpose the output tiles through the wave's private LDS tile, add the residual
+// and store whole rows (16 lanes x 16 B per row).
+template <int OT>
+__device__ __forceinline__ void store_tiles(const f32x16 (&o)[OT], float* abuf, const gnc_mlp_desc_t& d, int64_t row0,
+                                            int out_dim, int lane, int i, int h) {
+  const bool ovec = (d.ld_out % 4 == 0) && ((reinterpret_cast<uintptr_t>(d.out) & 15u) == 0);
+  const bool rvec = d.residual && (d.ld_residual % 4 == 0) && ((reinterpret_cast<uintptr_t>(d.residual) & 15u) == 0);
+  constexpr int OCH = (OT + 1) / 2;
+#pragma unroll
+  for (int cc = 0; cc < OCH; ++cc) {
+    if (cc * KC < out_dim) {
+      wave_lds_fence();
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const int t = 2 * cc + tt;
+        if (t < OT) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            f32x4 v = {o[t < OT ? t : 0][4 * q + 0], o[t < OT ? t : 0][4 * q + 1], o[t < OT ? t : 0][4 * q + 2],
+                       o[t < OT ? t : 0][4 * q + 3]};
+            *reinterpret_cast<f32x4*>(abuf + i * LDSW + 32 * tt + 8 * q + 4 * h) = v;
+          }
+        }
+      }
+      wave_lds_fence();
+      const int c4 = lane & 15;
+      const int rs = lane >> 4;
+      const int col = cc * KC + c4 * 4;
+      if (col < out_dim) {
+#pragma unroll
+        for (int p = 0; p < RPW / 4; ++p) {
+          const int j = p * 4 + rs;
+          const int64_t r = row0 + j;
+          if (r < d.rows) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(abuf + j * LDSW + c4 * 4);
+            if (d.residual) {
+              const f32x4 rv = load4_guarded(d.residual + r * d.ld_residual + col, col, out_dim, rvec);
+              v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+            }
+            float* po = d.out + r * d.ld_out + col;
+            if (ovec && col + 4 <= out_dim) {
+              *reinterpret_cast<f32x4*>(po) = v;
+            } else {
+              if (col + 0 < out_dim) po[0] = v.x;
+              if (col + 1 < out_dim) po[1] = v.y;
+              if (col + 2 < out_dim) po[2] = v.z;
+              if (col + 3 < out_dim) po[3] = v.w;
+            }
+          }
+        }
+      }
+    }
+  }
+  wave_lds_fence();
+}
+
+// smallest of {1,2,4,8} accumulator tiles (32 features each) covering `width`
+inline int tiles_for(int width) {
+  const int t = (width + 31) / 32;
+  return t <= 1 ? 1 : t <= 2 ? 2 : t <= 4 ? 4 : 8;
+}
+
+// host-side validation shared by both launchers (mlp_fused.hip)
+int validate_desc(const gnc_mlp_desc_t* d, bool check_ptrs);
+// resident-weights variant (mlp_resident.hip): returns GNC_ERR_UNSUPPORTED when the weights
+// do not fit in LDS, in which case the caller falls through to the streaming kernel
+int launch_resident(const gnc_mlp_desc_t& d, int T, bool narrow_out, hipStream_t stream, bool* launched);
+
+}  // namespace gnc_mlp
