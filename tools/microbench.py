@@ -76,6 +76,21 @@ def main():
     res["gather_ms"] = med
     res["gather_GBps"] = (8 * d * e + 4 * e) / med / 1e6
 
+    # PCIe-inclusive hand-over of one c3-sized batch (host tensors as the reference's loader yields them)
+    hx, hp, hei = torch.rand(n, 3), torch.rand(n, 2), torch.stack([row, col]).cpu()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    _ = hx.to(dev), hp.to(dev), hei.to(dev)
+    torch.cuda.synchronize()
+    res["h2d_pageable_ms"] = (time.perf_counter() - t0) * 1e3
+    hx, hp, hei = hx.pin_memory(), hp.pin_memory(), hei.pin_memory()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    _ = hx.to(dev, non_blocking=True), hp.to(dev, non_blocking=True), hei.to(dev, non_blocking=True)
+    torch.cuda.synchronize()
+    res["h2d_pinned_ms"] = (time.perf_counter() - t0) * 1e3
+    res["h2d_bytes"] = hx.numel() * 4 + hp.numel() * 4 + hei.numel() * 8
+
     if not a.skip_mlp:
         def lin(o, i):
             return torch.randn(o, i, device=dev) / i ** 0.5, torch.randn(o, device=dev) * 0.1
