@@ -11,13 +11,21 @@ utils/inference.py:59) never place tensors themselves.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 from torch import Tensor
 
 from . import functional as Fn
+from . import native
 from .MLP import MLP, default_device, require_gpu_param
 from .topology import GraphTopology, get_topology
+
+
+# Algebraic split of the edge processor's first Linear (DESIGN.md, K4 "W-split"); GNC_NO_WSPLIT=1
+# keeps the reference-form concat for A/B measurements.
+WSPLIT = os.environ.get("GNC_NO_WSPLIT") is None
 
 
 # --------------------------------------------------------------------------- a1 scatter_sum
@@ -63,7 +71,16 @@ class EdgeProcessor(nn.Module):
     def forward_sorted(self, x: Tensor, topo: GraphTopology, edge_attr: Tensor) -> Tensor:
         """Same math with the two row gathers fused into the kernel; ``edge_attr`` and the
         result are in destination-sorted edge order."""
-        return self.edge_processor.forward_segments(
+        mlp = self.edge_processor
+        norm = mlp.model[-1] if mlp.norm_type is not None else None
+        lin = mlp._linears()
+        if (WSPLIT and not isinstance(norm, nn.BatchNorm1d) and mlp.activation_name in native.ACTIVATIONS
+                and lin[0].in_features == 2 * x.size(1) + edge_attr.size(1) and x.size(1) % 4 == 0):
+            # W-split of the first Linear: node-side products once per node, gathered and added per edge
+            ln = (norm.weight, norm.bias, norm.eps) if isinstance(norm, nn.LayerNorm) else None
+            return Fn.edge_processor_wsplit(x, edge_attr, topo.src_sorted, topo.dst_sorted, [m.weight for m in lin],
+                                            [m.bias for m in lin], ln, mlp.activation_name, mlp._act_param())
+        return mlp.forward_segments(
             [(x, topo.src_sorted), (x, topo.dst_sorted), (edge_attr, None)], residual=edge_attr, rows=topo.num_edges)
 
 

@@ -136,6 +136,26 @@ __device__ __forceinline__ void mma_chunk_from_lds(f32x16 (&acc)[T], const float
   }
 }
 
+// acc[t][r] += X[i][feature(t, r, h)]: a staged [32][<=64] tile of rows that are already in the
+// hidden width is added to the pre-activation (GNC_SEG_ADD); `t0` = first accumulator tile the
+// 64 staged columns belong to.
+template <int T>
+__device__ __forceinline__ void add_rows_from_lds(f32x16 (&acc)[T], const float* abuf, int t0, int i, int h) {
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      if (t == t0 + tt) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(abuf + i * LDSW + 32 * tt + 8 * q + 4 * h);
+          acc[t][4 * q + 0] += v.x; acc[t][4 * q + 1] += v.y; acc[t][4 * q + 2] += v.z; acc[t][4 * q + 3] += v.w;
+        }
+      }
+    }
+  }
+}
+
 // dst[t] += W_chunk * src for the 64-column chunk `c` of a Linear whose input is the previous
 // layer's accumulators (register r of tile ts holds feature 32*ts + 8*(r>>2) + 4h + (r&3)).
 template <int TI, int TO>
@@ -194,9 +214,25 @@ __device__ __forceinline__ void layer_norm_tiles(f32x16 (&o)[OT], const float* p
 
 // Epilogue: transpose the output tiles through the wave's private LDS tile, add the residual
 // and store whole rows (16 lanes x 16 B per row).
+// true when the residual rows are exactly what the last staging step left in the wave's tile
+__device__ __forceinline__ bool residual_is_staged(const gnc_mlp_desc_t& d, int out_dim) {
+  const gnc_mlp_segment_t& ls = d.seg[d.num_segments - 1];
+  return d.residual && d.residual == ls.ptr && !ls.index && ls.width == out_dim && ls.ld == d.ld_residual &&
+         out_dim <= KC;
+}
+
 template <int OT>
-__device__ __forceinline__ void store_tiles(const f32x16 (&o)[OT], float* abuf, const gnc_mlp_desc_t& d, int64_t row0,
-                                            int out_dim, int lane, int i, int h) {
+__device__ __forceinline__ void store_tiles(f32x16 (&o)[OT], float* abuf, const gnc_mlp_desc_t& d, int64_t row0,
+                                            int out_dim, int lane, int i, int h, bool res_staged) {
+  if (res_staged) {  // residual straight from the staged input rows, in accumulator layout (no global re-read)
+#pragma unroll
+    for (int t = 0; t < OT && t < 2; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(abuf + i * LDSW + 32 * t + 8 * q + 4 * h);
+        o[t][4 * q + 0] += v.x; o[t][4 * q + 1] += v.y; o[t][4 * q + 2] += v.z; o[t][4 * q + 3] += v.w;
+      }
+  }
   const bool ovec = (d.ld_out % 4 == 0) && ((reinterpret_cast<uintptr_t>(d.out) & 15u) == 0);
   const bool rvec = d.residual && (d.ld_residual % 4 == 0) && ((reinterpret_cast<uintptr_t>(d.residual) & 15u) == 0);
   constexpr int OCH = (OT + 1) / 2;
@@ -227,7 +263,7 @@ __device__ __forceinline__ void store_tiles(const f32x16 (&o)[OT], float* abuf, 
           const int64_t r = row0 + j;
           if (r < d.rows) {
             f32x4 v = *reinterpret_cast<const f32x4*>(abuf + j * LDSW + c4 * 4);
-            if (d.residual) {
+            if (d.residual && !res_staged) {
               const f32x4 rv = load4_guarded(d.residual + r * d.ld_residual + col, col, out_dim, rvec);
               v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
             }
@@ -249,6 +285,8 @@ __device__ __forceinline__ void store_tiles(const f32x16 (&o)[OT], float* abuf, 
 }
 
 // smallest of {1,2,4,8} accumulator tiles (32 features each) covering `width`
+__host__ __device__ inline int ldw_of(const gnc_mlp_desc_t& d, int l) { return d.ld_weight[l] ? d.ld_weight[l] : d.in_dim[l]; }
+
 inline int tiles_for(int width) {
   const int t = (width + 31) / 32;
   return t <= 1 ? 1 : t <= 2 ? 2 : t <= 4 ? 4 : 8;

@@ -53,13 +53,13 @@ __device__ __forceinline__ void stage_rows(float* abuf, const gnc_mlp_segment_t&
 // dst[TO] += W_l * src[TI]   (src = previous layer's activations, in registers)
 template <int TI, int TO>
 __device__ __forceinline__ void linear_from_regs(f32x16 (&dst)[TO], const f32x16 (&src)[TI], float* wbuf,
-                                                 const float* __restrict__ W, int in_dim, int out_dim, bool vec_ok,
-                                                 int tid, int i, int h) {
+                                                 const float* __restrict__ W, int ldw, int in_dim, int out_dim,
+                                                 bool vec_ok, int tid, int i, int h) {
   constexpr int NCH = (TI + 1) / 2;  // 64-wide k chunks covering TI tiles
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     if (c * KC < in_dim) {  // workgroup-uniform
-      stage_weights<TO * 32, NT>(wbuf, W, in_dim, out_dim, c * KC, in_dim, 16, vec_ok, tid);
+      stage_weights<TO * 32, NT>(wbuf, W, ldw, out_dim, c * KC, in_dim, 16, vec_ok, tid);
       __syncthreads();
       mma_chunk_from_regs<TI, TO>(dst, src, wbuf, c, in_dim, i, h);
       __syncthreads();
@@ -88,7 +88,9 @@ __global__ __launch_bounds__(NT) void mlp_fused_kernel(const gnc_mlp_desc_t d, c
 
   unsigned wvec = 0;  // bit l: layer l's weight rows can be read with 16-B loads
   for (int l = 0; l < L; ++l)
-    if ((d.in_dim[l] % 4 == 0) && ((reinterpret_cast<uintptr_t>(d.weight[l]) & 15u) == 0)) wvec |= 1u << l;
+    if ((ldw_of(d, l) % 4 == 0) && ((reinterpret_cast<uintptr_t>(d.weight[l]) & 15u) == 0)) wvec |= 1u << l;
+
+  const bool res_staged = residual_is_staged(d, out_dim);
 
   for (int64_t tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
     const int64_t row0 = tile * RPB + wave * RPW;
@@ -97,23 +99,39 @@ __global__ __launch_bounds__(NT) void mlp_fused_kernel(const gnc_mlp_desc_t d, c
     f32x16 hid[HT];
     init_bias<HT>(hid, pbuf, h);
     {
-      int koff = 0;
       for (int s = 0; s < d.num_segments; ++s) {
         const gnc_mlp_segment_t seg = d.seg[s];
         const bool avec = (seg.ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(seg.ptr) & 15u) == 0);
+        if (seg.mode == GNC_SEG_ADD) {  // rows already in the hidden width: gather, add (wave-private, no barrier)
+          for (int c0 = 0; c0 < seg.width; c0 += KC) {
+            const int kc = seg.width - c0 < KC ? seg.width - c0 : KC;
+            wave_lds_fence();
+            stage_rows(abuf, seg, row0, d.rows, c0, 16, avec, lane);
+            (void)kc;
+            wave_lds_fence();
+            add_rows_from_lds<HT>(hid, abuf, c0 / 32, i, h);
+          }
+          wave_lds_fence();
+          continue;
+        }
+        const int koff = seg.wcol;
         const bool w0vec = (wvec & 1u) && (koff % 4 == 0);
         for (int c0 = 0; c0 < seg.width; c0 += KC) {
           const int kc = seg.width - c0 < KC ? seg.width - c0 : KC;
           const int kc8 = (kc + 7) >> 3;
-          stage_weights<HT * 32, NT>(wbuf, d.weight[0], d.in_dim[0], d.out_dim[0], koff + c0, koff + seg.width,
+          stage_weights<HT * 32, NT>(wbuf, d.weight[0], ldw_of(d, 0), d.out_dim[0], koff + c0, koff + seg.width,
                                      kc8 * 2, w0vec, tid);
           stage_rows(abuf, seg, row0, d.rows, c0, kc8 * 2, avec, lane);
           __syncthreads();
           mma_chunk_from_lds<HT>(hid, abuf, wbuf, kc8, i, h);
           __syncthreads();
         }
-        koff += seg.width;
       }
+    }
+    if (L == 1) {  // plain projection: the first Linear is also the last
+      if (d.ln_gamma) layer_norm_tiles<HT>(hid, pbuf + L * PSTRIDE, pbuf + (L + 1) * PSTRIDE, out_dim, d.ln_eps, h);
+      store_tiles<HT>(hid, abuf, d, row0, out_dim, lane, i, h, res_staged);
+      continue;
     }
     activate_tiles<HT>(hid, d.activation, d.act_param);
 
@@ -121,7 +139,8 @@ __global__ __launch_bounds__(NT) void mlp_fused_kernel(const gnc_mlp_desc_t d, c
     for (int l = 1; l < L - 1; ++l) {
       f32x16 nxt[HT];
       init_bias<HT>(nxt, pbuf + l * PSTRIDE, h);
-      linear_from_regs<HT, HT>(nxt, hid, wbuf, d.weight[l], d.in_dim[l], d.out_dim[l], (wvec >> l) & 1u, tid, i, h);
+      linear_from_regs<HT, HT>(nxt, hid, wbuf, d.weight[l], ldw_of(d, l), d.in_dim[l], d.out_dim[l], (wvec >> l) & 1u, tid,
+                               i, h);
       activate_tiles<HT>(nxt, d.activation, d.act_param);
 #pragma unroll
       for (int t = 0; t < HT; ++t) hid[t] = nxt[t];
@@ -130,9 +149,10 @@ __global__ __launch_bounds__(NT) void mlp_fused_kernel(const gnc_mlp_desc_t d, c
     // ------------------------------------------------------------------ last Linear, LayerNorm, store
     f32x16 o[OT];
     init_bias<OT>(o, pbuf + (L - 1) * PSTRIDE, h);
-    linear_from_regs<HT, OT>(o, hid, wbuf, d.weight[L - 1], d.in_dim[L - 1], out_dim, (wvec >> (L - 1)) & 1u, tid, i, h);
+    linear_from_regs<HT, OT>(o, hid, wbuf, d.weight[L - 1], ldw_of(d, L - 1), d.in_dim[L - 1], out_dim,
+                             (wvec >> (L - 1)) & 1u, tid, i, h);
     if (d.ln_gamma) layer_norm_tiles<OT>(o, pbuf + L * PSTRIDE, pbuf + (L + 1) * PSTRIDE, out_dim, d.ln_eps, h);
-    store_tiles<OT>(o, abuf, d, row0, out_dim, lane, i, h);
+    store_tiles<OT>(o, abuf, d, row0, out_dim, lane, i, h, res_staged);
   }
 }
 
@@ -162,8 +182,8 @@ int launch(const gnc_mlp_desc_t& d, hipStream_t stream) {
 
 int gnc_mlp::validate_desc(const gnc_mlp_desc_t* d, bool check_ptrs) {
   if (!d) { gnc::set_error("gnc_mlp: null descriptor"); return GNC_ERR_INVALID_ARGUMENT; }
-  if (d->num_segments < 1 || d->num_segments > GNC_MAX_SEGMENTS || d->num_linear < 2 || d->num_linear > GNC_MAX_LINEAR) {
-    gnc::set_error("gnc_mlp: need 1..%d segments and 2..%d Linear layers (got %d, %d)", GNC_MAX_SEGMENTS,
+  if (d->num_segments < 1 || d->num_segments > GNC_MAX_SEGMENTS || d->num_linear < 1 || d->num_linear > GNC_MAX_LINEAR) {
+    gnc::set_error("gnc_mlp: need 1..%d segments and 1..%d Linear layers (got %d, %d)", GNC_MAX_SEGMENTS,
                    GNC_MAX_LINEAR, d->num_segments, d->num_linear);
     return GNC_ERR_UNSUPPORTED;
   }
@@ -178,15 +198,28 @@ int gnc_mlp::validate_desc(const gnc_mlp_desc_t* d, bool check_ptrs) {
       return GNC_ERR_INVALID_ARGUMENT;
     }
     if (check_ptrs && d->rows > 0 && !d->seg[s].ptr) { gnc::set_error("gnc_mlp: segment %d null", s); return GNC_ERR_INVALID_ARGUMENT; }
+    if (d->seg[s].mode == GNC_SEG_ADD) {
+      if (d->seg[s].width != d->out_dim[0]) {
+        gnc::set_error("gnc_mlp: additive segment %d has width %d, first Linear has %d outputs", s, d->seg[s].width, d->out_dim[0]);
+        return GNC_ERR_INVALID_ARGUMENT;
+      }
+      continue;
+    }
+    if (d->seg[s].mode != GNC_SEG_MATMUL) { gnc::set_error("gnc_mlp: segment %d has unknown mode %d", s, d->seg[s].mode); return GNC_ERR_INVALID_ARGUMENT; }
+    if (d->seg[s].wcol < 0 || d->seg[s].wcol + d->seg[s].width > d->in_dim[0]) {
+      gnc::set_error("gnc_mlp: segment %d covers weight columns [%d, %d) outside [0, %d)", s, d->seg[s].wcol, d->seg[s].wcol + d->seg[s].width, d->in_dim[0]);
+      return GNC_ERR_INVALID_ARGUMENT;
+    }
     in0 += d->seg[s].width;
   }
   if (in0 != d->in_dim[0]) {
-    gnc::set_error("gnc_mlp: segment widths sum to %lld but in_dim[0] is %d", (long long)in0, d->in_dim[0]);
+    gnc::set_error("gnc_mlp: matmul segment widths sum to %lld but in_dim[0] is %d", (long long)in0, d->in_dim[0]);
     return GNC_ERR_INVALID_ARGUMENT;
   }
   const int H = d->out_dim[0];
   for (int l = 0; l < d->num_linear; ++l) {
     if (d->in_dim[l] < 1 || d->out_dim[l] < 1) { gnc::set_error("gnc_mlp: layer %d has empty dims", l); return GNC_ERR_INVALID_ARGUMENT; }
+    if (d->ld_weight[l] != 0 && d->ld_weight[l] < d->in_dim[l]) { gnc::set_error("gnc_mlp: ld_weight[%d] < in_dim", l); return GNC_ERR_INVALID_ARGUMENT; }
     if (l > 0 && d->in_dim[l] != d->out_dim[l - 1]) {
       gnc::set_error("gnc_mlp: layer %d in_dim %d != layer %d out_dim %d", l, d->in_dim[l], l - 1, d->out_dim[l - 1]);
       return GNC_ERR_INVALID_ARGUMENT;

@@ -1,16 +1,32 @@
 // K4, weights-resident variant of the fused MLP (formulation: see mlp_fused.hip).
 //
 // When every Linear's weights fit in the 160 KB LDS of a CU (hidden width <= 64: the config-c3
-// model needs 5 chunks x 64 x 68 floats = 87 KB for the edge processor) the kernel keeps them
-// there for its whole life: one persistent 8-wave workgroup per CU stages all weight chunks
-// once, and from then on the waves never meet at a barrier again.  Each wave walks its own
-// 32-row tiles; the only per-tile memory traffic is the tile's input rows and its output rows.
+// model) the kernel keeps them there for its whole life: one persistent 8-wave workgroup per
+// CU stages all weight chunks once, and from then on the waves never meet at a barrier again.
+// Each wave walks its own 32-row tiles; the only per-tile memory traffic is the tile's input
+// rows and its output rows.
 //
-// Latency hiding is explicit: the global loads of step k+1 (one step = one 64-column chunk of
-// one concat segment of one tile) are issued into registers before the MFMAs of step k run, and
-// the gather indices are fetched two steps ahead with one coalesced load per step, so the
-// dependent chain index -> row address -> row never sits on the critical path.  Two waves per
-// SIMD cover each other's LDS writes, LayerNorm and epilogue with MFMA work.
+// Per-tile schedule (one "step" = the <=64 columns of one concat segment for the tile's rows):
+//   MATMUL steps first  - rows land in registers, go to the wave's LDS tile, feed MFMAs;
+//                         the loads of the NEXT step are issued before the MFMAs start;
+//   one combined ADD step - the W-split's pre-projected rows (ps[src], pd[dst]) are summed in
+//                         registers, staged once and added to the pre-activation; their loads
+//                         fly under the last MATMUL step's MFMAs;
+//   the first step's rows of the NEXT tile are requested right after that and have the
+//   remaining Linear layers, LayerNorm and epilogue (>= 8k cycles) to land.  Gather ids are
+//   fetched one tile earlier still, with one coalesced load per segment and tile.
+//
+// Two things make the register prefetch actually overlap on gfx950 (hipcc 7.2):
+//   * gfx9 counts loads and stores in ONE vmcnt and hipcc falls back to `s_waitcnt vmcnt(0)`
+//     whenever both kinds are pending, which would drain every prefetch at its first use.  The
+//     output stores are therefore issued from inline asm (invisible to that bookkeeping;
+//     loads still complete in order among themselves, so the compiler's counted waits stay
+//     correct - they can only over-wait).
+//   * every load is unconditional: row ids are clamped instead of predicated (rows past the end
+//     produce values that are never stored), so there is no exec-masked VMEM in the loop.
+// Requirements checked by the launcher (anything else runs the streaming kernel): ReLU,
+// all tables / weights / output 16-B aligned with leading dimensions % 4 == 0, every segment
+// <= 64 columns, MATMUL segments listed before ADD segments, out width % 4 == 0, rows < 2^31.
 #include <stdlib.h>
 
 #include "mlp_device.h"
@@ -21,164 +37,284 @@ namespace {
 
 constexpr int RWAVES = 8;
 constexpr int RNT = RWAVES * 64;
+constexpr int NP = RPW / 4;  // row groups per staging pass: 16 lanes x 16 B per row, 4 rows per instruction
 
-struct Step {  // one staging/compute step of a wave: tile `wt`, concat segment `s`, column offset `c0`
-  int64_t wt;
-  int s;
-  int c0;
+__device__ __forceinline__ void compiler_lds_barrier() {
+  // LDS operations of one wave execute in issue order, so a later ds_read sees an earlier
+  // ds_write of another lane without any wait; only the COMPILER must not reorder them.
+  asm volatile("" ::: "memory");
+}
+
+// 16-B store of the lanes whose bit is set in `mask`, issued behind the compiler's back.
+__device__ __forceinline__ void hidden_store_b128(float* p, f32x4 v, unsigned long long mask) {
+  unsigned long long saved;
+  asm volatile(
+      "s_and_saveexec_b64 %0, %1\n\t"
+      "global_store_dwordx4 %2, %3, off\n\t"
+      "s_mov_b64 exec, %0\n\t"
+      "s_nop 1"
+      : "=&s"(saved)
+      : "s"(mask), "v"(p), "v"(v)
+      : "memory");
+}
+
+template <int T>
+__device__ __forceinline__ void relu_tiles(f32x16 (&acc)[T]) {
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = fmaxf(acc[t][r], 0.f);
+}
+
+template <int T>
+__device__ __forceinline__ void add_tile_from_lds(f32x16 (&acc)[T], const float* abuf, int i, int h) {
+#pragma unroll
+  for (int t = 0; t < T && t < 2; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(abuf + i * LDSW + 32 * t + 8 * q + 4 * h);
+      acc[t][4 * q + 0] += v.x; acc[t][4 * q + 1] += v.y; acc[t][4 * q + 2] += v.z; acc[t][4 * q + 3] += v.w;
+    }
+}
+
+template <int T>
+__device__ __forceinline__ void tiles_to_lds(const f32x16 (&o)[T], float* abuf, int i, int h) {
+#pragma unroll
+  for (int t = 0; t < T && t < 2; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 v = {o[t][4 * q + 0], o[t][4 * q + 1], o[t][4 * q + 2], o[t][4 * q + 3]};
+      *reinterpret_cast<f32x4*>(abuf + i * LDSW + 32 * t + 8 * q + 4 * h) = v;
+    }
+}
+
+struct SegView {  // wave-uniform view of one segment
+  const float* ptr;
+  const int32_t* index;
+  int ld;
+  int width;
 };
 
-template <int HT, int OT>
-__global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t d, const int64_t num_wtiles,
+// HT/OT: accumulator tiles of the hidden / output width.  NMM: MATMUL steps per tile (1..3).
+// NADD: additive segments merged into one step (0 or 2).  RESREG: the residual is the table of
+// the LAST MATMUL step (no index): its rows are kept in registers instead of being re-read.
+template <int HT, int OT, int NMM, int NADD, bool RESREG>
+__global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t d, const int num_wtiles,
                                                            const int total_chunks) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int WT = HT > OT ? HT : OT;
   constexpr int CH = WT * 32 * LDSW;  // floats per resident weight chunk
   constexpr int PSTRIDE = WT * 32;
+  constexpr int NS = NMM + NADD;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 31;
   const int h = lane >> 5;
-  const int c4 = lane & 15;  // staging role: 16 lanes x 16 B cover one 64-float row chunk
+  const int c4 = lane & 15;
   const int rs = lane >> 4;
   const int L = d.num_linear;
-  const int nseg = d.num_segments;
   const int out_dim = d.out_dim[L - 1];
+  const int rows = (int)d.rows;
   float* wres = lds;
   float* pbuf = lds + total_chunks * CH;
   float* abuf = pbuf + (L + 2) * PSTRIDE + wave * RPW * LDSW;
 
   // ---- one-time: parameters and every weight chunk into LDS ---------------------------------
   stage_params<RNT>(pbuf, d, PSTRIDE, tid);
-  int l0_chunks = 0;
   {
-    int chunk = 0, koff = 0;
-    const bool w0v = (d.in_dim[0] % 4 == 0) && ((reinterpret_cast<uintptr_t>(d.weight[0]) & 15u) == 0);
-    for (int s = 0; s < nseg; ++s) {
-      const int width = d.seg[s].width;
-      for (int c0 = 0; c0 < width; c0 += KC, ++chunk)
-        stage_weights<WT * 32, RNT>(wres + chunk * CH, d.weight[0], d.in_dim[0], d.out_dim[0], koff + c0, koff + width,
-                                    16, w0v && (koff % 4 == 0), tid);
-      koff += width;
-    }
-    l0_chunks = chunk;
+    int chunk = 0;
+    const int ldw0 = ldw_of(d, 0);
+    const bool w0v = (ldw0 % 4 == 0) && ((reinterpret_cast<uintptr_t>(d.weight[0]) & 15u) == 0);
+#pragma unroll
+    for (int s = 0; s < NMM; ++s, ++chunk)
+      stage_weights<WT * 32, RNT>(wres + chunk * CH, d.weight[0], ldw0, d.out_dim[0], d.seg[s].wcol,
+                                  d.seg[s].wcol + d.seg[s].width, 16, w0v && (d.seg[s].wcol % 4 == 0), tid);
     for (int l = 1; l < L; ++l) {
-      const bool wv = (d.in_dim[l] % 4 == 0) && ((reinterpret_cast<uintptr_t>(d.weight[l]) & 15u) == 0);
+      const int ldw = ldw_of(d, l);
+      const bool wv = (ldw % 4 == 0) && ((reinterpret_cast<uintptr_t>(d.weight[l]) & 15u) == 0);
       for (int c = 0; c * KC < d.in_dim[l]; ++c, ++chunk)
-        stage_weights<WT * 32, RNT>(wres + chunk * CH, d.weight[l], d.in_dim[l], d.out_dim[l], c * KC, d.in_dim[l], 16,
-                                    wv, tid);
+        stage_weights<WT * 32, RNT>(wres + chunk * CH, d.weight[l], ldw, d.out_dim[l], c * KC, d.in_dim[l], 16, wv, tid);
     }
   }
-  const int hid_chunks = (d.in_dim[1] + KC - 1) / KC;  // every Linear after the first has in_dim = H
   __syncthreads();
 
-  // ---- per-wave pipeline over (tile, segment, column chunk) steps ----------------------------
-  const int64_t total_waves = (int64_t)gridDim.x * RWAVES;
-
-  auto advance = [&](Step c) {
-    c.c0 += KC;
-    if (c.c0 >= d.seg[c.s].width) {
-      c.c0 = 0;
-      if (++c.s >= nseg) { c.s = 0; c.wt += total_waves; }
-    }
-    return c;
-  };
-  // row ids of the step's 32 rows, one per lane (lanes 32..63 mirror 0..31): ONE coalesced load
-  auto load_idx = [&](const Step& c) -> int {
-    const int64_t r = c.wt * RPW + (lane & 31);
-    int v = (int)r;
-    const int32_t* ip = d.seg[c.s].index;
-    if (ip && c.wt < num_wtiles && r < d.rows) v = ip[r];
-    return v;
-  };
-  auto load_rows = [&](f32x4 (&pre)[RPW / 4], const Step& c, int idxv) {
-    const gnc_mlp_segment_t seg = d.seg[c.s];
-    const bool vec = (seg.ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(seg.ptr) & 15u) == 0);
-    const int col = c.c0 + c4 * 4;
+  SegView sv[NS];
 #pragma unroll
-    for (int p = 0; p < RPW / 4; ++p) {
-      const int j = p * 4 + rs;
-      const int tr = __shfl(idxv, j, 64);
-      const int64_t r = c.wt * RPW + j;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (c.wt < num_wtiles && r < d.rows) v = load4_guarded(seg.ptr + (int64_t)tr * seg.ld + col, col, seg.width, vec);
-      pre[p] = v;
+  for (int s = 0; s < NS; ++s) sv[s] = {d.seg[s].ptr, d.seg[s].index, d.seg[s].ld, d.seg[s].width};
+
+  // ---- per-wave pipeline -----------------------------------------------------------------------
+  const int total_waves = (int)gridDim.x * RWAVES;
+  const int last_wt = num_wtiles - 1;
+
+  // table row of tile row (lane & 31); clamped so the load is always legal
+  auto load_idx = [&](int wt, const SegView& s) -> int {
+    const int wtc = wt < last_wt ? wt : last_wt;
+    int r = wtc * RPW + (lane & 31);
+    r = r < rows ? r : rows - 1;
+    return s.index ? s.index[r] : r;
+  };
+  // the step's rows: lane (rs, c4) gets 16 B of row p*4+rs for p = 0..7; no predication
+  auto load_rows = [&](f32x4 (&pre)[NP], const SegView& s, int idxv) {
+    const int col = c4 * 4 < s.ld ? c4 * 4 : 0;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int tr = __shfl(idxv, p * 4 + rs, 64);
+      pre[p] = *reinterpret_cast<const f32x4*>(s.ptr + (int64_t)tr * s.ld + col);
     }
   };
+  // registers -> the wave's LDS tile; columns at or beyond the segment width become zero
+  auto stage = [&](const f32x4 (&pre)[NP], int width) {
+    compiler_lds_barrier();
+    const int c = c4 * 4;
+    if (width >= KC) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) *reinterpret_cast<f32x4*>(abuf + (p * 4 + rs) * LDSW + c) = pre[p];
+    } else {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        f32x4 v = pre[p];
+        v.x = c + 0 < width ? v.x : 0.f; v.y = c + 1 < width ? v.y : 0.f;
+        v.z = c + 2 < width ? v.z : 0.f; v.w = c + 3 < width ? v.w : 0.f;
+        *reinterpret_cast<f32x4*>(abuf + (p * 4 + rs) * LDSW + c) = v;
+      }
+    }
+    compiler_lds_barrier();
+  };
 
-  Step c1 = {(int64_t)blockIdx.x * RWAVES + wave, 0, 0};
-  f32x4 pre[RPW / 4];
-  load_rows(pre, c1, load_idx(c1));
-  Step c2 = advance(c1);
-  int idx2 = load_idx(c2);
+  int wt = (int)blockIdx.x * RWAVES + wave;
+  f32x4 cur[NP];                  // rows of the step about to be staged
+  f32x4 keep[RESREG ? NP : 1];    // residual rows (copy of the last MATMUL step)
+  f32x4 addA[NADD ? NP : 1], addB[NADD ? NP : 1];
+  // gather ids: id0 = segment 0 of the NEXT tile, ids[s>=1] = segment s of the CURRENT tile
+  int ids[NS];
+  load_rows(cur, sv[0], load_idx(wt, sv[0]));
+#pragma unroll
+  for (int s = 1; s < NS; ++s) ids[s] = load_idx(wt, sv[s]);
+  int id0 = load_idx(wt + total_waves, sv[0]);
 
-  while (c1.wt < num_wtiles) {
-    const int64_t row0 = c1.wt * RPW;
+  while (wt < num_wtiles) {
+    const int row0 = wt * RPW;
+    const int nwt = wt + total_waves;
 
-    // ------------------------------------------------------------------ layer 0 over the staged steps
+    // ------------------------------------------------------------------ first Linear
     f32x16 hid[HT];
     init_bias<HT>(hid, pbuf, h);
-    for (int chunk = 0; chunk < l0_chunks; ++chunk) {
-      const int kc = d.seg[c1.s].width - c1.c0 < KC ? d.seg[c1.s].width - c1.c0 : KC;
-      const int kc8 = (kc + 7) >> 3;
-      wave_lds_fence();
 #pragma unroll
-      for (int p = 0; p < RPW / 4; ++p) *reinterpret_cast<f32x4*>(abuf + (p * 4 + rs) * LDSW + c4 * 4) = pre[p];
-      wave_lds_fence();
-      load_rows(pre, c2, idx2);  // next step's rows fly while this step's MFMAs run
-      const Step c3 = advance(c2);
-      const int idx3 = load_idx(c3);
-      mma_chunk_from_lds<HT>(hid, abuf, wres + chunk * CH, kc8, i, h);
-      c1 = c2;
-      c2 = c3;
-      idx2 = idx3;
+    for (int s = 0; s < NMM; ++s) {
+      stage(cur, sv[s].width);
+      if constexpr (RESREG) if (s == NMM - 1) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) keep[p] = cur[p];
+      }
+      // request what comes next before the MFMAs of this step start
+      if (s + 1 < NMM) {
+        load_rows(cur, sv[s + 1 < NMM ? s + 1 : 0], ids[s + 1 < NMM ? s + 1 : 0]);
+        ids[s + 1 < NMM ? s + 1 : 0] = load_idx(nwt, sv[s + 1 < NMM ? s + 1 : 0]);
+      } else {
+        if constexpr (NADD > 0) {
+          load_rows(addA, sv[NMM], ids[NMM]);
+          load_rows(addB, sv[NMM + 1], ids[NMM + 1]);
+          ids[NMM] = load_idx(nwt, sv[NMM]);
+          ids[NMM + 1] = load_idx(nwt, sv[NMM + 1]);
+        } else {
+          load_rows(cur, sv[0], id0);
+          id0 = load_idx(nwt + total_waves, sv[0]);
+        }
+      }
+      mma_chunk_from_lds<HT>(hid, abuf, wres + s * CH, (sv[s].width + 7) >> 3, i, h);
     }
-    activate_tiles<HT>(hid, d.activation, d.act_param);
-
-    // ------------------------------------------------------------------ hidden layers 1 .. L-2 (weights resident)
-    for (int l = 1; l < L - 1; ++l) {
-      f32x16 nxt[HT];
-      init_bias<HT>(nxt, pbuf + l * PSTRIDE, h);
-      const float* wl = wres + (l0_chunks + (l - 1) * hid_chunks) * CH;
+    if constexpr (NADD > 0) {
+      f32x4 sum[NP];
 #pragma unroll
-      for (int c = 0; c < (HT + 1) / 2; ++c)
-        if (c * KC < d.in_dim[l]) mma_chunk_from_regs<HT, HT>(nxt, hid, wl + c * CH, c, d.in_dim[l], i, h);
-      activate_tiles<HT>(nxt, d.activation, d.act_param);
-#pragma unroll
-      for (int t = 0; t < HT; ++t) hid[t] = nxt[t];
+      for (int p = 0; p < NP; ++p) sum[p] = addA[p] + addB[p];
+      stage(sum, sv[NMM].width);
+      load_rows(cur, sv[0], id0);  // next tile's first step: the rest of this tile to land
+      id0 = load_idx(nwt + total_waves, sv[0]);
+      add_tile_from_lds<HT>(hid, abuf, i, h);
     }
 
-    // ------------------------------------------------------------------ last Linear, LayerNorm, store
-    f32x16 o[OT];
-    init_bias<OT>(o, pbuf + (L - 1) * PSTRIDE, h);
+    if (L == 1) {  // plain projection
+      if (d.ln_gamma) layer_norm_tiles<HT>(hid, pbuf + L * PSTRIDE, pbuf + (L + 1) * PSTRIDE, out_dim, d.ln_eps, h);
+      compiler_lds_barrier();
+      tiles_to_lds<HT>(hid, abuf, i, h);
+    } else {
+      relu_tiles<HT>(hid);
+      // ---------------------------------------------------------------- hidden layers 1 .. L-2
+      for (int l = 1; l < L - 1; ++l) {
+        f32x16 nxt[HT];
+        init_bias<HT>(nxt, pbuf + l * PSTRIDE, h);
+        mma_chunk_from_regs<HT, HT>(nxt, hid, wres + (NMM + l - 1) * CH, 0, d.in_dim[l], i, h);
+        relu_tiles<HT>(nxt);
+#pragma unroll
+        for (int t = 0; t < HT; ++t) hid[t] = nxt[t];
+      }
+      // ---------------------------------------------------------------- last Linear, LayerNorm
+      f32x16 o[OT];
+      init_bias<OT>(o, pbuf + (L - 1) * PSTRIDE, h);
+      mma_chunk_from_regs<HT, OT>(o, hid, wres + (NMM + L - 2) * CH, 0, d.in_dim[L - 1], i, h);
+      if (d.ln_gamma) layer_norm_tiles<OT>(o, pbuf + L * PSTRIDE, pbuf + (L + 1) * PSTRIDE, out_dim, d.ln_eps, h);
+      compiler_lds_barrier();
+      tiles_to_lds<OT>(o, abuf, i, h);
+    }
+    compiler_lds_barrier();
+    // The compiler's counted vmcnt waits do not know about the asm stores below; make it collect the
+    // next tile's prefetched rows (issued >= one Linear ago) BEFORE the stores join the queue, so that
+    // no later wait for them has to sit out the stores as well.
+#pragma unroll
+    for (int p = 0; p < NP; ++p) asm volatile("" ::"v"(cur[p]));
+
+    // ------------------------------------------------------------------ epilogue: whole rows out
     {
-      const float* wl = wres + (l0_chunks + (L - 2) * hid_chunks) * CH;
+      const int col = c4 * 4;
+      const bool col_ok = col < out_dim;  // out_dim % 4 == 0 (launcher)
+      f32x4 outv[NP];
 #pragma unroll
-      for (int c = 0; c < (HT + 1) / 2; ++c)
-        if (c * KC < d.in_dim[L - 1]) mma_chunk_from_regs<HT, OT>(o, hid, wl + c * CH, c, d.in_dim[L - 1], i, h);
+      for (int p = 0; p < NP; ++p) {
+        outv[p] = *reinterpret_cast<const f32x4*>(abuf + (p * 4 + rs) * LDSW + col);
+        if constexpr (RESREG) outv[p] += keep[p];
+      }
+      if (!RESREG && d.residual) {  //  // rows this tile has just read: L2 hits; unconditional, clamped
+        const int rc = col < d.ld_residual ? col : 0;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          int r = row0 + p * 4 + rs;
+          r = r < rows ? r : rows - 1;
+          outv[p] += *reinterpret_cast<const f32x4*>(d.residual + (int64_t)r * d.ld_residual + rc);
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int r = row0 + p * 4 + rs;
+        const unsigned long long m = __ballot(col_ok && r < rows);
+        hidden_store_b128(d.out + (int64_t)(r < rows ? r : rows - 1) * d.ld_out + (col_ok ? col : 0), outv[p], m);
+      }
     }
-    if (d.ln_gamma) layer_norm_tiles<OT>(o, pbuf + L * PSTRIDE, pbuf + (L + 1) * PSTRIDE, out_dim, d.ln_eps, h);
-    store_tiles<OT>(o, abuf, d, row0, out_dim, lane, i, h);
+    compiler_lds_barrier();
+    wt = nwt;
   }
 }
 
-template <int HT, int OT>
+template <int HT, int OT, int NMM, int NADD, bool RESREG>
 int launch(const gnc_mlp_desc_t& d, int total_chunks, size_t smem, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    int rc = gnc::check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_resident_kernel<HT, OT>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
-                            "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    int rc = gnc::check_hip(
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_resident_kernel<HT, OT, NMM, NADD, RESREG>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+        "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc) return rc;
     attr_set = true;
   }
   const int64_t num_wtiles = gnc::ceil_div(d.rows, RPW);
   int64_t grid = gnc::ceil_div(num_wtiles, RWAVES);
   if (grid > gnc::kNumCU) grid = gnc::kNumCU;  // one persistent workgroup per CU
-  mlp_resident_kernel<HT, OT><<<dim3((unsigned)grid), dim3(RNT), smem, stream>>>(d, num_wtiles, total_chunks);
+  mlp_resident_kernel<HT, OT, NMM, NADD, RESREG>
+      <<<dim3((unsigned)grid), dim3(RNT), smem, stream>>>(d, (int)num_wtiles, total_chunks);
   return gnc::check_launch("mlp_resident_kernel");
 }
+
+bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace
 
@@ -186,15 +322,50 @@ int gnc_mlp::launch_resident(const gnc_mlp_desc_t& d, int T, bool narrow_out, hi
   *launched = false;
   static const bool disabled = getenv("GNC_MLP_NO_RESIDENT") != nullptr;  // A/B switch for benchmarking
   if (disabled) return GNC_OK;
-  if (T > 2 || d.rows >= INT32_MAX) return GNC_OK;  // wider layers never fit: streaming kernel
+  if (T > 2 || narrow_out || d.rows >= INT32_MAX) return GNC_OK;
   const int L = d.num_linear;
-  int total_chunks = 0;
-  for (int s = 0; s < d.num_segments; ++s) total_chunks += (d.seg[s].width + KC - 1) / KC;
-  total_chunks += (L - 1) * ((d.in_dim[1] + KC - 1) / KC);
+  const int od = d.out_dim[L - 1];
+  if (L > 1 && d.activation != GNC_ACT_RELU) return GNC_OK;
+  // shape of the step schedule: MATMUL segments first, then exactly 0 or 2 ADD segments
+  int nmm = 0, nadd = 0;
+  for (int s = 0; s < d.num_segments; ++s) {
+    const gnc_mlp_segment_t& g = d.seg[s];
+    if (g.width > KC || g.ld % 4 != 0 || !al16(g.ptr)) return GNC_OK;
+    if (g.mode == GNC_SEG_ADD) {
+      ++nadd;
+    } else {
+      if (nadd) return GNC_OK;  // a MATMUL segment after an ADD one
+      ++nmm;
+    }
+  }
+  if (nmm < 1 || nmm > 3 || (nadd != 0 && !(nadd == 2 && nmm == 1))) return GNC_OK;
+  if (od % 4 != 0 || d.ld_out % 4 != 0 || !al16(d.out)) return GNC_OK;
+  if (d.residual && (d.ld_residual % 4 != 0 || !al16(d.residual))) return GNC_OK;
+  if (L > 1 && d.in_dim[1] > KC) return GNC_OK;
+
+  const int total_chunks = nmm + (L - 1);
   const size_t floats = (size_t)total_chunks * T * 32 * LDSW + (size_t)(L + 2) * T * 32 + (size_t)RWAVES * RPW * LDSW;
   const size_t smem = floats * sizeof(float);
   if (smem > 160 * 1024) return GNC_OK;
-  *launched = true;
-  if (T == 1) return launch<1, 1>(d, total_chunks, smem, stream);
-  return narrow_out ? launch<2, 1>(d, total_chunks, smem, stream) : launch<2, 2>(d, total_chunks, smem, stream);
+
+  const gnc_mlp_segment_t& lm = d.seg[nmm - 1];
+  const bool resreg = d.residual && d.residual == lm.ptr && !lm.index && lm.ld == d.ld_residual && lm.width == od;
+
+#define GNC_RES(HT_, NMM_, NADD_)                                                             \
+  do {                                                                                        \
+    *launched = true;                                                                         \
+    return resreg ? launch<HT_, HT_, NMM_, NADD_, true>(d, total_chunks, smem, stream)        \
+                  : launch<HT_, HT_, NMM_, NADD_, false>(d, total_chunks, smem, stream);      \
+  } while (0)
+  if (T == 2) {
+    if (nadd == 2) GNC_RES(2, 1, 2);
+    if (nmm == 1) GNC_RES(2, 1, 0);
+    if (nmm == 2) GNC_RES(2, 2, 0);
+    GNC_RES(2, 3, 0);
+  }
+  if (nadd == 2) GNC_RES(1, 1, 2);
+  if (nmm == 1) GNC_RES(1, 1, 0);
+  if (nmm == 2) GNC_RES(1, 2, 0);
+  GNC_RES(1, 3, 0);
+#undef GNC_RES
 }

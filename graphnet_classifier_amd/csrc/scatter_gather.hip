@@ -148,10 +148,10 @@ __global__ __launch_bounds__(gnc::kBlock) void gather_rows_scalar(const float* _
 __global__ __launch_bounds__(gnc::kBlock) void edge_features_kernel(const float* __restrict__ pos, int32_t space_dim,
                                                                     const int32_t* __restrict__ src,
                                                                     const int32_t* __restrict__ dst,
-                                                                    int64_t num_edges, float* __restrict__ out) {
+                                                                    int64_t num_edges, float* __restrict__ out,
+                                                                    int64_t od) {
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  const int od = space_dim + 1;
   for (; e < num_edges; e += stride) {
     const float* ps = pos + (int64_t)src[e] * space_dim;
     const float* pd = pos + (int64_t)dst[e] * space_dim;
@@ -162,6 +162,7 @@ __global__ __launch_bounds__(gnc::kBlock) void edge_features_kernel(const float*
       dist += fabsf(rel);  // summed in dimension order like torch.sum(dim=1) on a short row
     }
     out[e * od + space_dim] = dist;
+    for (int64_t d = space_dim + 1; d < od; ++d) out[e * od + d] = 0.f;
   }
 }
 
@@ -258,14 +259,15 @@ extern "C" int gnc_gather_rows_f32(const float* table, int64_t ld_table, const i
 }
 
 extern "C" int gnc_edge_features_f32(const float* pos, int32_t space_dim, const int32_t* src, const int32_t* dst,
-                                     int64_t num_edges, float* out, void* stream_) {
-  GNC_REQUIRE(num_edges >= 0 && space_dim >= 1 && space_dim <= 16, "gnc_edge_features_f32: bad sizes");
+                                     int64_t num_edges, float* out, int64_t ld_out, void* stream_) {
+  GNC_REQUIRE(num_edges >= 0 && space_dim >= 1 && space_dim <= 16 && ld_out >= space_dim + 1,
+              "gnc_edge_features_f32: bad sizes");
   if (num_edges == 0) return GNC_OK;
   GNC_REQUIRE(pos && src && dst && out, "gnc_edge_features_f32: null pointer");
   int64_t blocks = gnc::ceil_div(num_edges, gnc::kBlock);
   const int64_t cap = gnc::kNumCU * 16;
   if (blocks > cap) blocks = cap;
   edge_features_kernel<<<dim3((unsigned)blocks), dim3(gnc::kBlock), 0, (hipStream_t)stream_>>>(pos, space_dim, src, dst,
-                                                                                               num_edges, out);
+                                                                                               num_edges, out, ld_out);
   return gnc::check_launch("edge_features_kernel");
 }

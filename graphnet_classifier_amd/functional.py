@@ -128,6 +128,55 @@ def fused_mlp(segments, weights, biases, ln=None, activation: str = "ReLU", act_
     return _FusedMLP.apply(meta, *args)
 
 
+class _EdgeProcessorWSplit(torch.autograd.Function):
+    """EdgeProcessor (models/GNN.py:57-64) on destination-sorted edges with the first Linear
+    split algebraically:  W0 [x_src | x_dst | e]^T = Ws x[src] + Wd x[dst] + We e.
+    Two per-NODE projection launches (num_linear == 1, no bias) + one per-EDGE launch whose
+    first two segments are gathered and ADDED.  args = x, e, weights[L], biases[L], gamma, beta."""
+
+    @staticmethod
+    def forward(ctx, meta, x, e, *params):
+        src, dst, num_linear, activation, act_param, ln_eps, has_ln = meta
+        weights, biases = list(params[:num_linear]), list(params[num_linear:2 * num_linear])
+        ln = (params[2 * num_linear], params[2 * num_linear + 1], ln_eps) if has_ln else None
+        dn = x.size(1)
+        w0 = weights[0]
+        ps = native.mlp_forward([(x, None)], [w0[:, :dn]], [None])           # [N, H] = x Ws^T
+        pd = native.mlp_forward([(x, None)], [w0[:, dn:2 * dn]], [None])     # [N, H] = x Wd^T
+        out = native.mlp_forward([(ps, src), (pd, dst), (e, None)], [w0[:, 2 * dn:]] + weights[1:], biases, ln=ln,
+                                 activation=activation, act_param=act_param, residual=e, rows=e.size(0),
+                                 modes=[native.SEG_ADD, native.SEG_ADD, native.SEG_MATMUL])
+        ctx.meta = meta
+        ctx.save_for_backward(x, e, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        src, dst, num_linear, activation, act_param, ln_eps, has_ln = ctx.meta
+        need = ctx.needs_input_grad[1:]
+        leaves = [a.detach().requires_grad_(bool(n)) for a, n in zip(ctx.saved_tensors, need)]
+        x, e, params = leaves[0], leaves[1], leaves[2:]
+        act = _torch_activation(activation, act_param)
+        with torch.enable_grad():
+            h = torch.cat([x[src.long()], x[dst.long()], e], dim=-1)
+            for k in range(num_linear):
+                h = F.linear(h, params[k], params[num_linear + k])
+                if k + 1 < num_linear:
+                    h = act(h)
+            if has_ln:
+                h = F.layer_norm(h, (h.size(-1),), params[2 * num_linear], params[2 * num_linear + 1], ln_eps)
+            h = h + e
+            wanted = [t for t, n in zip(leaves, need) if n]
+            grads = iter(torch.autograd.grad(h, wanted, grad_out.contiguous(), allow_unused=True))
+        return (None,) + tuple(next(grads) if n else None for n in need)
+
+
+def edge_processor_wsplit(x, e, src, dst, weights, biases, ln, activation="ReLU", act_param=0.0):
+    meta = (src, dst, len(weights), activation, float(act_param), float(ln[2]) if ln is not None else 0.0, ln is not None)
+    args = list(weights) + list(biases) + ([ln[0], ln[1]] if ln is not None else [])
+    return _EdgeProcessorWSplit.apply(meta, x, e, *args)
+
+
 def edge_features(pos: torch.Tensor, src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
     """[pos[dst]-pos[src], L1 norm] per edge (models/GNN.py:299-302).  ``pos`` is input data
     (utils/dataloader.py:50); gradients with respect to it are not provided."""

@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 GNC_MAX_SEGMENTS = 4
 GNC_MAX_LINEAR = 8
-ABI_VERSION = 1
+ABI_VERSION = 4
 
 ACTIVATIONS = {  # nn.<Name> accepted by the reference's MLP(activation=...) (models/MLP.py:21)
     "ReLU": 0, "Identity": 1, "Tanh": 2, "Sigmoid": 3, "SiLU": 4, "GELU": 5, "LeakyReLU": 6, "ELU": 7,
@@ -35,7 +35,7 @@ _SIGNATURES = {
     "gnc_scatter_sum_csr_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p,
                                           c_int64, c_void_p]),
     "gnc_gather_rows_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p]),
-    "gnc_edge_features_f32": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "gnc_edge_features_f32": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     "gnc_sizeof_mlp_desc": (c_size_t, []),
     "gnc_mlp_supported": (c_int32, [c_void_p]),
     "gnc_mlp_forward_f32": (c_int32, [c_void_p, c_void_p]),
@@ -44,14 +44,16 @@ EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 
 class MlpSegment(Structure):
-    _fields_ = [("ptr", c_void_p), ("index", c_void_p), ("width", c_int32), ("ld", c_int32)]
+    _fields_ = [("ptr", c_void_p), ("index", c_void_p), ("width", c_int32), ("ld", c_int32), ("mode", c_int32),
+                ("wcol", c_int32)]
 
 
 class MlpDesc(Structure):
     _fields_ = [
         ("num_segments", c_int32), ("num_linear", c_int32), ("activation", c_int32), ("act_param", c_float),
         ("seg", MlpSegment * GNC_MAX_SEGMENTS),
-        ("weight", c_void_p * GNC_MAX_LINEAR), ("bias", c_void_p * GNC_MAX_LINEAR),
+        ("weight", c_void_p * GNC_MAX_LINEAR), ("ld_weight", c_int32 * GNC_MAX_LINEAR),
+        ("bias", c_void_p * GNC_MAX_LINEAR),
         ("in_dim", c_int32 * GNC_MAX_LINEAR), ("out_dim", c_int32 * GNC_MAX_LINEAR),
         ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ln_eps", c_float),
         ("residual", c_void_p), ("ld_residual", c_int32),
@@ -236,18 +238,19 @@ def edge_features(pos: torch.Tensor, src: torch.Tensor, dst: torch.Tensor) -> to
     _require_cuda(pos, src, dst)
     pos = pos.float().contiguous()
     e, sd = src.numel(), pos.size(1)
-    out = torch.empty(e, sd + 1, dtype=torch.float32, device=pos.device)
+    ld = (sd + 1 + 3) // 4 * 4  # rows padded to a multiple of 16 B (zeros) for the MLP kernels' vector loads
+    buf = torch.empty(e, ld, dtype=torch.float32, device=pos.device)
     with torch.cuda.device(pos.device):
-        _check(lib.gnc_edge_features_f32(pos.data_ptr(), sd, src.data_ptr(), dst.data_ptr(), e, out.data_ptr(),
+        _check(lib.gnc_edge_features_f32(pos.data_ptr(), sd, src.data_ptr(), dst.data_ptr(), e, buf.data_ptr(), ld,
                                          _stream(pos)), "gnc_edge_features_f32")
-    return out
+    return buf[:, :sd + 1]
 
 
 # --------------------------------------------------------------------------- K4
 def make_mlp_desc(segments, weights, biases, ln, activation: str, act_param: float, residual, out, rows: int):
-    """Fill a gnc_mlp_desc_t.  ``segments`` = [(table, index_or_None, width)], tensors must stay
+    """Fill a gnc_mlp_desc_t.  ``segments`` = [(table, index_or_None, width, mode, wcol)], tensors must stay
     alive until the call returns (they are enqueued on the current stream)."""
-    if len(segments) > GNC_MAX_SEGMENTS or not (2 <= len(weights) <= GNC_MAX_LINEAR):
+    if len(segments) > GNC_MAX_SEGMENTS or not (1 <= len(weights) <= GNC_MAX_LINEAR):
         raise NotImplementedError(f"MLP with {len(segments)} segments / {len(weights)} Linear layers is outside the HIP kernel")
     if activation not in ACTIVATIONS:
         raise NotImplementedError(f"activation nn.{activation} has no HIP kernel (supported: {sorted(ACTIVATIONS)})")
@@ -256,13 +259,16 @@ def make_mlp_desc(segments, weights, biases, ln, activation: str, act_param: flo
     d.num_linear = len(weights)
     d.activation = ACTIVATIONS[activation]
     d.act_param = act_param
-    for s, (table, index, width) in enumerate(segments):
+    for s, (table, index, width, mode, wcol) in enumerate(segments):
+        d.seg[s].wcol = wcol
         d.seg[s].ptr = table.data_ptr()
         d.seg[s].index = index.data_ptr() if index is not None else None
         d.seg[s].width = width
         d.seg[s].ld = _ld(table)
+        d.seg[s].mode = mode
     for l, (w, b) in enumerate(zip(weights, biases)):
         d.weight[l] = w.data_ptr()
+        d.ld_weight[l] = _ld(w)
         d.bias[l] = b.data_ptr() if b is not None else None
         d.out_dim[l], d.in_dim[l] = w.shape
     if ln is not None:
@@ -274,21 +280,37 @@ def make_mlp_desc(segments, weights, biases, ln, activation: str, act_param: flo
     return d
 
 
+SEG_MATMUL, SEG_ADD = 0, 1
+
+
 def mlp_forward(segments, weights, biases, ln=None, activation: str = "ReLU", act_param: float = 0.0,
-                residual: torch.Tensor | None = None, rows: int | None = None) -> torch.Tensor:
-    """Fused MLP.  segments: list of (table [*, w] fp32, index int32 [rows] | None)."""
+                residual: torch.Tensor | None = None, rows: int | None = None, modes=None) -> torch.Tensor:
+    """Fused MLP.  segments (in CONCAT order): list of (table [*, w] fp32, index int32 [rows] | None);
+    ``modes[s]`` is SEG_MATMUL (default) or SEG_ADD.  Weights may be column slices of a larger
+    matrix.  The segment that is also the residual is listed last for the kernel (its weight
+    columns are carried in ``wcol``), so the residual comes from the staged rows."""
     lib = load_library()
-    segs = []
-    for table, index in segments:
+    modes = list(modes) if modes is not None else [SEG_MATMUL] * len(segments)
+    segs, wcol = [], 0
+    for (table, index), mode in zip(segments, modes):
         _require_cuda(table, index)
         table = _rowmajor(table)
         if index is not None and index.dtype != torch.int32:
             raise TypeError("segment index must be int32")
-        segs.append((table, index, table.size(1)))
+        segs.append((table, index, table.size(1), mode, wcol if mode == SEG_MATMUL else 0))
+        if mode == SEG_MATMUL:
+            wcol += table.size(1)
+    # kernel-side order: MATMUL segments first (the one that is also the residual last among them, so
+    # its rows can stay in registers for the residual add), then the additive segments
+    def _rank(sg):
+        is_res = (residual is not None and sg[1] is None and sg[0].data_ptr() == residual.data_ptr()
+                  and sg[0].shape == residual.shape)
+        return (sg[3] == SEG_ADD, is_res)
+    segs.sort(key=_rank)
     if rows is None:
-        t0, i0, _ = segs[0]
+        t0, i0 = segments[0]
         rows = i0.numel() if i0 is not None else t0.size(0)
-    weights = [w.contiguous() for w in weights]
+    weights = [_rowmajor(w) for w in weights]
     biases = [b.contiguous() if b is not None else None for b in biases]
     dev = segs[0][0].device
     out = torch.empty(rows, weights[-1].size(0), dtype=torch.float32, device=dev)
@@ -298,7 +320,9 @@ def mlp_forward(segments, weights, biases, ln=None, activation: str = "ReLU", ac
     # executed FLOPs of this launch: 2 * rows * sum(in*out) over the Linear layers
     flops = 2.0 * rows * sum(w.size(0) * w.size(1) for w in weights)
     with torch.cuda.device(dev):
-        _check(_launch(f"mlp_fused_in{weights[0].size(1)}_h{weights[0].size(0)}_out{weights[-1].size(0)}", out,
+        nadd = sum(1 for m in modes if m == SEG_ADD)
+        _check(_launch(f"mlp_fused_in{weights[0].size(1)}{'+%dadd' % nadd if nadd else ''}_h{weights[0].size(0)}"
+                       f"_out{weights[-1].size(0)}_L{len(weights)}", out,
                        lambda: lib.gnc_mlp_forward_f32(ctypes.byref(desc), _stream(out)), flops),
                "gnc_mlp_forward_f32")
     return out

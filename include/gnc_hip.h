@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GNC_ABI_VERSION 1
+#define GNC_ABI_VERSION 4
 
 enum {
   GNC_OK = 0,
@@ -95,10 +95,12 @@ int gnc_gather_rows_f32(const float* table, int64_t ld_table, const int32_t* ind
 
 /* ---- K6: edge features ------------------------------------------------------------------
  * Replaces models/GNN.py:299-302:  rel = pos[dst[e]] - pos[src[e]];  out[e] = [rel, sum|rel|].
- * pos is [N, space_dim]; out is [E, space_dim + 1].
+ * pos is [N, space_dim]; out is [E, ld_out] with ld_out >= space_dim + 1; columns past the
+ * features are written as zero (ld_out = 4 for space_dim = 2 gives 16-B rows the MLP kernels can
+ * load with one vector instruction).
  */
 int gnc_edge_features_f32(const float* pos, int32_t space_dim, const int32_t* src, const int32_t* dst,
-                          int64_t num_edges, float* out, void* stream);
+                          int64_t num_edges, float* out, int64_t ld_out, void* stream);
 
 /* ---- K4: fused MLP ----------------------------------------------------------------------
  * Replaces `MLP.forward` (models/MLP.py:45-47 over the Sequential built at :24-37) together
@@ -113,14 +115,30 @@ int gnc_edge_features_f32(const float* pos, int32_t space_dim, const int32_t* sr
  *
  * Weights are nn.Linear layout [out_dim, in_dim] row-major (state-dict tensors are passed
  * as they are).  fp32 in, fp32 MFMA (v_mfma_f32_32x32x2_f32), fp32 out.
- * Limits: hidden widths and out width <= 256, 2 <= num_linear <= GNC_MAX_LINEAR, all
+ * Limits: hidden widths and out width <= 256, 1 <= num_linear <= GNC_MAX_LINEAR, all
  * hidden layers the same width (true by construction in models/MLP.py:24-27).
+ * in_dim[0] is the summed width of the GNC_SEG_MATMUL segments.  When `residual` is the table of
+ * the LAST listed segment (no index, same ld, width == out width <= 64) the kernel takes the
+ * residual from the rows it has already staged instead of reading them again.  num_linear == 1 is a plain
+ * (optionally LayerNorm-ed) projection.
+ *
+ * W-split.  W0 [x_src | x_dst | e]^T = Ws x[src] + Wd x[dst] + We e: the node-side products can
+ * be formed once per NODE (two num_linear == 1 launches over [N, Dn]) and merely gathered and
+ * added per EDGE (GNC_SEG_ADD segments), which removes 2/3 of the first Linear's per-edge MFMA
+ * work of models/GNN.py:58-61.  ld_weight lets We be passed as a column slice of W0.
  */
+enum { GNC_SEG_MATMUL = 0, /* columns of the virtual concat: multiplied by their slice of weight[0]      */
+       GNC_SEG_ADD = 1     /* rows already projected to the hidden width: added to the first Linear's
+                              pre-activation (width must equal out_dim[0]); see "W-split" below       */ };
+
 typedef struct gnc_mlp_segment {
   const float* ptr;     /* [*, ld] table                                   */
   const int32_t* index; /* NULL, or [rows] row ids into the table          */
   int32_t width;        /* columns taken from the table                    */
   int32_t ld;           /* leading dimension of the table (elements)       */
+  int32_t mode;         /* GNC_SEG_MATMUL | GNC_SEG_ADD                    */
+  int32_t wcol;         /* MATMUL: first column of weight[0] this segment multiplies (segments may be
+                           listed, i.e. staged, in any order; the concat order lives here)          */
 } gnc_mlp_segment_t;
 
 typedef struct gnc_mlp_desc {
@@ -130,6 +148,7 @@ typedef struct gnc_mlp_desc {
   float act_param;      /* negative slope / alpha for LEAKY_RELU / ELU     */
   gnc_mlp_segment_t seg[GNC_MAX_SEGMENTS];
   const float* weight[GNC_MAX_LINEAR]; /* [out_dim[l], in_dim[l]]          */
+  int32_t ld_weight[GNC_MAX_LINEAR];   /* row stride of weight[l]; 0 = in_dim[l] (contiguous) */
   const float* bias[GNC_MAX_LINEAR];   /* [out_dim[l]] or NULL             */
   int32_t in_dim[GNC_MAX_LINEAR];
   int32_t out_dim[GNC_MAX_LINEAR];

@@ -227,6 +227,45 @@ def test_mlp_other_activations(native, act):
     assert max_abs(y.cpu(), ref) < 2e-5
 
 
+@pytest.mark.parametrize("d,out", [(16, 16), (64, 64), (64, 128), (128, 128), (96, 40)])
+def test_single_linear_projection(native, d, out):
+    """num_linear == 1: plain projection x W^T (+ b), used by the W-split of the edge processor."""
+    rng = np.random.default_rng(d + out)
+    x = torch.from_numpy(rng.standard_normal((333, d)).astype(np.float32))
+    w = torch.from_numpy((rng.standard_normal((out, d)) / np.sqrt(d)).astype(np.float32))
+    b = torch.from_numpy(rng.standard_normal(out).astype(np.float32))
+    y = native.mlp_forward([(x.to(DEV), None)], [w.to(DEV)], [None])
+    assert max_abs(y.cpu(), x @ w.t()) < 1e-5
+    yb = native.mlp_forward([(x.to(DEV), None)], [w.to(DEV)], [b.to(DEV)])
+    assert max_abs(yb.cpu(), x @ w.t() + b) < 1e-5
+    # weight given as a column slice of a wider matrix (ld_weight > in_dim)
+    wide = torch.from_numpy((rng.standard_normal((out, 3 * d)) / np.sqrt(d)).astype(np.float32)).to(DEV)
+    ys = native.mlp_forward([(x.to(DEV), None)], [wide[:, d:2 * d]], [None])
+    assert max_abs(ys.cpu(), x @ wide[:, d:2 * d].cpu().t()) < 1e-5
+
+
+@pytest.mark.parametrize("d", [16, 64, 128])
+def test_mlp_additive_segments_equal_concat_form(native, d):
+    """W-split: Ws x[src] + Wd x[dst] gathered and ADDED == first Linear on cat[x[src], x[dst], e]."""
+    rng = np.random.default_rng(d * 3)
+    n, e = 211, 1500
+    sd = _mlp_sd(rng, 3 * d, d, d, 2, True)
+    x = torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32))
+    ea = torch.from_numpy(rng.standard_normal((e, d)).astype(np.float32))
+    ei = torch.from_numpy(rng.integers(0, n, size=(2, e)).astype(np.int32))
+    w0 = sd["m.model.0.weight"].to(DEV)
+    ws = [w0[:, 2 * d:], sd["m.model.2.weight"].to(DEV), sd["m.model.4.weight"].to(DEV)]
+    bs = [sd[f"m.model.{i}.bias"].to(DEV) for i in (0, 2, 4)]
+    ln = (sd["m.model.5.weight"].to(DEV), sd["m.model.5.bias"].to(DEV), 1e-5)
+    xd = x.to(DEV)
+    ps = native.mlp_forward([(xd, None)], [w0[:, :d]], [None])
+    pd = native.mlp_forward([(xd, None)], [w0[:, d:2 * d]], [None])
+    y = native.mlp_forward([(ps, ei[0].to(DEV)), (pd, ei[1].to(DEV)), (ea.to(DEV), None)], ws, bs, ln=ln,
+                           residual=ea.to(DEV), modes=[native.SEG_ADD, native.SEG_ADD, native.SEG_MATMUL])
+    ref = O.mlp_forward(sd, "m", torch.cat([x[ei[0].long()], x[ei[1].long()], ea], -1)) + ea
+    assert max_abs(y.cpu(), ref) < 1e-5
+
+
 def test_mlp_rejects_unsupported(native):
     x = torch.zeros(4, 8, device=DEV)
     w = [torch.zeros(300, 8, device=DEV), torch.zeros(4, 300, device=DEV)]

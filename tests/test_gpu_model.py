@@ -200,6 +200,23 @@ def test_full_size_workload_against_oracle_on_sampled_graphs(G, name, scale):
     assert torch.equal(y, y2)
 
 
+def test_wsplit_and_reference_form_agree(G, monkeypatch):
+    """The algebraic split of the edge processor's first Linear only reorders fp32 sums."""
+    from graphnet_classifier_amd import synthetic as S
+    batch = S.superpixel_like_graphs(5, seed=3)
+    for width in (32, 64, 128):
+        torch.manual_seed(width)
+        m = G.GraphNet(**S.graphnet_kwargs(width, 2))
+        with torch.no_grad():
+            monkeypatch.setattr(G, "WSPLIT", True)
+            a = m(batch.x, batch.pos, batch.edge_index)
+            monkeypatch.setattr(G, "WSPLIT", False)
+            b = m(batch.x, batch.pos, batch.edge_index)
+        assert max_abs(a, b) < 5e-6
+        sd = {k: v.cpu() for k, v in m.state_dict().items()}
+        assert max_abs(a, O.graphnet_forward(sd, batch.x, batch.pos, batch.edge_index)) < TOL
+
+
 def test_forward_on_cpu_module_fails_loudly(G):
     m = G.GraphNet(**{"n_blocks": 1}).to("cpu")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
