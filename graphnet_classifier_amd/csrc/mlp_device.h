@@ -174,6 +174,9 @@ __device__ __forceinline__ void mma_chunk_from_regs(f32x16 (&dst)[TO], const f32
         dst[t] = mfma(a.z, src[ts < TI ? ts : 0][4 * q + 2], dst[t]);
         dst[t] = mfma(a.w, src[ts < TI ? ts : 0][4 * q + 3], dst[t]);
       }
+      // wide layers: stop hipcc from hoisting every A fragment of the unrolled chunk to the top
+      // (64 x ds_read_b128 = 256 live registers at 8 tiles); one k-group of fragments at a time
+      if constexpr (TO >= 4) __builtin_amdgcn_sched_barrier(0);
     }
   }
 }
@@ -284,6 +287,94 @@ __device__ __forceinline__ void store_tiles(f32x16 (&o)[OT], float* abuf, const 
   wave_lds_fence();
 }
 
+// ---- helpers of the FAST (ReLU, aligned, unconditional-load) kernels ---------------------------------
+constexpr int NP = RPW / 4;  // row groups per staging pass: 16 lanes x 16 B per row, 4 rows per instruction
+
+__device__ __forceinline__ void compiler_lds_barrier() {
+  // LDS operations of one wave execute in issue order, so a later ds_read sees an earlier
+  // ds_write of another lane without any wait; only the COMPILER must not reorder them.
+  asm volatile("" ::: "memory");
+}
+
+// 16-B store of the lanes whose bit is set in `mask`, issued behind the compiler's back.
+__device__ __forceinline__ void hidden_store_b128(float* p, f32x4 v, unsigned long long mask) {
+  unsigned long long saved;
+  asm volatile(
+      "s_and_saveexec_b64 %0, %1\n\t"
+      "global_store_dwordx4 %2, %3, off\n\t"
+      "s_mov_b64 exec, %0\n\t"
+      "s_nop 1"
+      : "=&s"(saved)
+      : "s"(mask), "v"(p), "v"(v)
+      : "memory");
+}
+
+// one float of the lanes in `mask`, same reason as hidden_store_b128
+__device__ __forceinline__ void hidden_store_b32(float* p, float v, unsigned long long mask) {
+  unsigned long long saved;
+  asm volatile(
+      "s_and_saveexec_b64 %0, %1\n\t"
+      "global_store_dword %2, %3, off\n\t"
+      "s_mov_b64 exec, %0\n\t"
+      "s_nop 1"
+      : "=&s"(saved)
+      : "s"(mask), "v"(p), "v"(v)
+      : "memory");
+}
+
+// one output row group: 16-B store when the row layout allows it, else up to four masked scalar stores
+__device__ __forceinline__ void store_row_piece(float* rowp, int col, f32x4 v, bool row_ok, int out_dim, bool vec_out) {
+  if (vec_out) {
+    const bool ok = row_ok && col < out_dim;
+    hidden_store_b128(rowp + (ok ? col : 0), v, __ballot(ok));
+  } else {
+    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool ok = row_ok && col + k < out_dim;
+      hidden_store_b32(rowp + (ok ? col + k : 0), e[k], __ballot(ok));
+    }
+  }
+}
+
+template <int T>
+__device__ __forceinline__ void relu_tiles(f32x16 (&acc)[T]) {
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = fmaxf(acc[t][r], 0.f);
+}
+
+template <int T>
+__device__ __forceinline__ void add_tile_from_lds(f32x16 (&acc)[T], const float* abuf, int i, int h) {
+#pragma unroll
+  for (int t = 0; t < T && t < 2; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(abuf + i * LDSW + 32 * t + 8 * q + 4 * h);
+      acc[t][4 * q + 0] += v.x; acc[t][4 * q + 1] += v.y; acc[t][4 * q + 2] += v.z; acc[t][4 * q + 3] += v.w;
+    }
+}
+
+template <int T>
+__device__ __forceinline__ void tiles_to_lds(const f32x16 (&o)[T], float* abuf, int i, int h) {
+#pragma unroll
+  for (int t = 0; t < T && t < 2; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 v = {o[t][4 * q + 0], o[t][4 * q + 1], o[t][4 * q + 2], o[t][4 * q + 3]};
+      *reinterpret_cast<f32x4*>(abuf + i * LDSW + 32 * t + 8 * q + 4 * h) = v;
+    }
+}
+
+struct SegView {  // wave-uniform view of one segment
+  const float* ptr;
+  const int32_t* index;
+  int ld;
+  int width;
+};
+
+
 // smallest of {1,2,4,8} accumulator tiles (32 features each) covering `width`
 __host__ __device__ inline int ldw_of(const gnc_mlp_desc_t& d, int l) { return d.ld_weight[l] ? d.ld_weight[l] : d.in_dim[l]; }
 
@@ -297,5 +388,7 @@ int validate_desc(const gnc_mlp_desc_t* d, bool check_ptrs);
 // resident-weights variant (mlp_resident.hip): returns GNC_ERR_UNSUPPORTED when the weights
 // do not fit in LDS, in which case the caller falls through to the streaming kernel
 int launch_resident(const gnc_mlp_desc_t& d, int T, bool narrow_out, hipStream_t stream, bool* launched);
+// streaming FAST variant (mlp_stream.hip) for widths whose weights do not fit in LDS; same contract
+int launch_stream(const gnc_mlp_desc_t& d, int T, bool narrow_out, hipStream_t stream, bool* launched);
 
 }  // namespace gnc_mlp

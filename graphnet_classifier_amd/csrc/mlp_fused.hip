@@ -259,6 +259,8 @@ extern "C" int gnc_mlp_forward_f32(const gnc_mlp_desc_t* desc, void* stream_) {
   bool launched = false;  // weights-resident variant first (decides by LDS fit)
   rc = launch_resident(*desc, T, narrow_out, stream, &launched);
   if (rc || launched) return rc;
+  rc = launch_stream(*desc, T, narrow_out, stream, &launched);  // wide layers: double-buffered weight stream
+  if (rc || launched) return rc;
 
   switch (T * 2 + (narrow_out ? 1 : 0)) {
     case 1 * 2 + 0: case 1 * 2 + 1: return launch<1, 1>(*desc, stream);

@@ -37,63 +37,6 @@ namespace {
 
 constexpr int RWAVES = 8;
 constexpr int RNT = RWAVES * 64;
-constexpr int NP = RPW / 4;  // row groups per staging pass: 16 lanes x 16 B per row, 4 rows per instruction
-
-__device__ __forceinline__ void compiler_lds_barrier() {
-  // LDS operations of one wave execute in issue order, so a later ds_read sees an earlier
-  // ds_write of another lane without any wait; only the COMPILER must not reorder them.
-  asm volatile("" ::: "memory");
-}
-
-// 16-B store of the lanes whose bit is set in `mask`, issued behind the compiler's back.
-__device__ __forceinline__ void hidden_store_b128(float* p, f32x4 v, unsigned long long mask) {
-  unsigned long long saved;
-  asm volatile(
-      "s_and_saveexec_b64 %0, %1\n\t"
-      "global_store_dwordx4 %2, %3, off\n\t"
-      "s_mov_b64 exec, %0\n\t"
-      "s_nop 1"
-      : "=&s"(saved)
-      : "s"(mask), "v"(p), "v"(v)
-      : "memory");
-}
-
-template <int T>
-__device__ __forceinline__ void relu_tiles(f32x16 (&acc)[T]) {
-#pragma unroll
-  for (int t = 0; t < T; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = fmaxf(acc[t][r], 0.f);
-}
-
-template <int T>
-__device__ __forceinline__ void add_tile_from_lds(f32x16 (&acc)[T], const float* abuf, int i, int h) {
-#pragma unroll
-  for (int t = 0; t < T && t < 2; ++t)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(abuf + i * LDSW + 32 * t + 8 * q + 4 * h);
-      acc[t][4 * q + 0] += v.x; acc[t][4 * q + 1] += v.y; acc[t][4 * q + 2] += v.z; acc[t][4 * q + 3] += v.w;
-    }
-}
-
-template <int T>
-__device__ __forceinline__ void tiles_to_lds(const f32x16 (&o)[T], float* abuf, int i, int h) {
-#pragma unroll
-  for (int t = 0; t < T && t < 2; ++t)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      f32x4 v = {o[t][4 * q + 0], o[t][4 * q + 1], o[t][4 * q + 2], o[t][4 * q + 3]};
-      *reinterpret_cast<f32x4*>(abuf + i * LDSW + 32 * t + 8 * q + 4 * h) = v;
-    }
-}
-
-struct SegView {  // wave-uniform view of one segment
-  const float* ptr;
-  const int32_t* index;
-  int ld;
-  int width;
-};
 
 // HT/OT: accumulator tiles of the hidden / output width.  NMM: MATMUL steps per tile (1..3).
 // NADD: additive segments merged into one step (0 or 2).  RESREG: the residual is the table of
@@ -267,7 +210,8 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
     // ------------------------------------------------------------------ epilogue: whole rows out
     {
       const int col = c4 * 4;
-      const bool col_ok = col < out_dim;  // out_dim % 4 == 0 (launcher)
+      const bool col_ok = col < out_dim;
+      const bool vec_out = (out_dim % 4 == 0) && (d.ld_out % 4 == 0) && ((reinterpret_cast<uintptr_t>(d.out) & 15u) == 0);
       f32x4 outv[NP];
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
@@ -286,8 +230,8 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
         const int r = row0 + p * 4 + rs;
-        const unsigned long long m = __ballot(col_ok && r < rows);
-        hidden_store_b128(d.out + (int64_t)(r < rows ? r : rows - 1) * d.ld_out + (col_ok ? col : 0), outv[p], m);
+        store_row_piece(d.out + (int64_t)(r < rows ? r : rows - 1) * d.ld_out, col, outv[p], r < rows && col_ok, out_dim,
+                        vec_out);
       }
     }
     compiler_lds_barrier();
@@ -322,7 +266,7 @@ int gnc_mlp::launch_resident(const gnc_mlp_desc_t& d, int T, bool narrow_out, hi
   *launched = false;
   static const bool disabled = getenv("GNC_MLP_NO_RESIDENT") != nullptr;  // A/B switch for benchmarking
   if (disabled) return GNC_OK;
-  if (T > 2 || narrow_out || d.rows >= INT32_MAX) return GNC_OK;
+  if (T > 2 || d.rows >= INT32_MAX) return GNC_OK;
   const int L = d.num_linear;
   const int od = d.out_dim[L - 1];
   if (L > 1 && d.activation != GNC_ACT_RELU) return GNC_OK;
@@ -339,7 +283,6 @@ int gnc_mlp::launch_resident(const gnc_mlp_desc_t& d, int T, bool narrow_out, hi
     }
   }
   if (nmm < 1 || nmm > 3 || (nadd != 0 && !(nadd == 2 && nmm == 1))) return GNC_OK;
-  if (od % 4 != 0 || d.ld_out % 4 != 0 || !al16(d.out)) return GNC_OK;
   if (d.residual && (d.ld_residual % 4 != 0 || !al16(d.residual))) return GNC_OK;
   if (L > 1 && d.in_dim[1] > KC) return GNC_OK;
 
@@ -357,6 +300,12 @@ int gnc_mlp::launch_resident(const gnc_mlp_desc_t& d, int T, bool narrow_out, hi
     return resreg ? launch<HT_, HT_, NMM_, NADD_, true>(d, total_chunks, smem, stream)        \
                   : launch<HT_, HT_, NMM_, NADD_, false>(d, total_chunks, smem, stream);      \
   } while (0)
+  if (narrow_out) {  // out width <= 32 (the decoder): one output tile
+    if (resreg || nadd || nmm != 1) return GNC_OK;
+    *launched = true;
+    return T == 2 ? launch<2, 1, 1, 0, false>(d, total_chunks, smem, stream)
+                  : launch<1, 1, 1, 0, false>(d, total_chunks, smem, stream);
+  }
   if (T == 2) {
     if (nadd == 2) GNC_RES(2, 1, 2);
     if (nmm == 1) GNC_RES(2, 1, 0);

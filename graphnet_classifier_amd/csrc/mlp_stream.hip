@@ -1,0 +1,440 @@
+// K4, streaming FAST variant of the fused MLP for hidden widths 65..256 (formulation: mlp_fused.hip).
+//
+// The weights of a 128- or 256-wide MLP do not fit in LDS (edge processor at D=128: 192 KB), so
+// they stream L2 -> registers -> LDS in [features][64 k] chunks through a DOUBLE buffer: while the
+// waves run the MFMAs of chunk q out of buffer q&1, every thread already holds its share of chunk
+// q+1 in registers (loads issued before the MFMAs) and drops it into buffer (q+1)&1 afterwards;
+// one barrier per chunk then publishes it.  The chunk sequence of a tile (first Linear's MATMUL
+// chunks, then every later Linear) is the same for every tile, so the stream never stops: the
+// last chunk of a tile prefetches chunk 0 of the next.
+//
+// The per-wave side is the resident kernel's pipeline (mlp_resident.hip): unconditional, clamped
+// row loads one step ahead in registers, gather ids one tile ahead, additive (W-split) segments
+// summed in registers, hidden activations in accumulators across layers, stores issued from inline
+// asm so hipcc's vmcnt waits stay counted.
+#include <stdlib.h>
+
+#include "mlp_device.h"
+
+using namespace gnc_mlp;
+
+namespace {
+
+constexpr int MAX_STEPS = 16;
+constexpr int MAX_WCHUNKS = 40;
+
+struct StreamPlan {
+  int num_steps;    // first-Linear staging steps per tile
+  int num_wchunks;  // weight chunks per tile
+  struct {
+    short seg;   // segment staged by this step
+    short seg2;  // second segment of a combined ADD step, or -1
+    short c0;    // first column of the 64-column chunk
+    short add;   // 1 = additive step (no weights)
+  } step[MAX_STEPS];
+  struct {
+    short layer;
+    short kbase;   // first weight column of the chunk
+    short klimit;  // columns at or beyond this are zero
+    short pad;
+  } wc[MAX_WCHUNKS];
+};
+
+// tiles [T0, T0+2) of the accumulator <-> the 64 staged columns
+template <int T, int TA, int TT>
+__device__ __forceinline__ void add_one_tile_from_lds(f32x16 (&acc)[T], const float* abuf, int i, int h) {
+  if constexpr (TA < T) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(abuf + i * LDSW + 32 * TT + 8 * q + 4 * h);
+      acc[TA][4 * q + 0] += v.x; acc[TA][4 * q + 1] += v.y; acc[TA][4 * q + 2] += v.z; acc[TA][4 * q + 3] += v.w;
+    }
+  }
+}
+template <int T, int T0>
+__device__ __forceinline__ void add_chunk_from_lds(f32x16 (&acc)[T], const float* abuf, int i, int h) {
+  add_one_tile_from_lds<T, T0, 0>(acc, abuf, i, h);
+  add_one_tile_from_lds<T, T0 + 1, 1>(acc, abuf, i, h);
+}
+
+template <int T, int TA, int TT>
+__device__ __forceinline__ void one_tile_to_lds(const f32x16 (&o)[T], float* abuf, int i, int h) {
+  if constexpr (TA < T) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 v = {o[TA][4 * q + 0], o[TA][4 * q + 1], o[TA][4 * q + 2], o[TA][4 * q + 3]};
+      *reinterpret_cast<f32x4*>(abuf + i * LDSW + 32 * TT + 8 * q + 4 * h) = v;
+    }
+  }
+}
+template <int T, int T0>
+__device__ __forceinline__ void chunk_to_lds(const f32x16 (&o)[T], float* abuf, int i, int h) {
+  one_tile_to_lds<T, T0, 0>(o, abuf, i, h);
+  one_tile_to_lds<T, T0 + 1, 1>(o, abuf, i, h);
+}
+
+// ADD2: additive segments are staged in pairs summed in registers (needs a second row set; off for the
+// 256-wide instance, which has no registers to spare).
+// DBUF: two weight buffers and one barrier per chunk; false (256-wide layers, whose 70 KB chunks do not
+// fit twice): one buffer, the prefetched registers are written between two barriers.
+template <int HT, int OT, int WAVES, bool DBUF, bool ADD2>
+__global__ __launch_bounds__(WAVES * 64) void mlp_stream_kernel(const gnc_mlp_desc_t d, const StreamPlan pl,
+                                                                const int num_tiles) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int NT = WAVES * 64;
+  constexpr int WT = HT > OT ? HT : OT;
+  constexpr int CH = WT * 32 * LDSW;          // floats per weight chunk buffer
+  constexpr int PSTRIDE = WT * 32;
+  constexpr int RPP = NT / 16;                // weight rows staged per pass
+  constexpr int NW = (WT * 32) / RPP;         // float4 registers per thread for one weight chunk
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 31;
+  const int h = lane >> 5;
+  const int c4 = lane & 15;
+  const int rs = lane >> 4;
+  const int wc4 = tid & 15;  // weight staging role
+  const int wr0 = tid >> 4;
+  const int L = d.num_linear;
+  const int out_dim = d.out_dim[L - 1];
+  const int rows = (int)d.rows;
+  float* wbuf = lds;                              // [DBUF ? 2 : 1][CH]
+  float* pbuf = lds + (DBUF ? 2 : 1) * CH;
+  float* abuf = pbuf + (L + 2) * PSTRIDE + wave * RPW * LDSW;
+
+  stage_params<NT>(pbuf, d, PSTRIDE, tid);
+
+  // this thread's share of weight chunk q -> registers (unconditional loads, zero outside the matrix)
+  auto wload = [&](f32x4 (&wr)[NW], int q) {
+    const int layer = pl.wc[q].layer;
+    const float* W = d.weight[layer];
+    const int ldw = ldw_of(d, layer);
+    const int nrows = d.out_dim[layer];
+    const int klimit = pl.wc[q].klimit;
+    const int col = pl.wc[q].kbase + wc4 * 4;
+    const int colc = col < klimit ? col : pl.wc[q].kbase;
+#pragma unroll
+    for (int p = 0; p < NW; ++p) {
+      const int n = p * RPP + wr0;
+      const int nc = n < nrows ? n : nrows - 1;
+      f32x4 v = *reinterpret_cast<const f32x4*>(W + (int64_t)nc * ldw + colc);
+      const bool rowok = n < nrows;
+      v.x = (rowok && col + 0 < klimit) ? v.x : 0.f; v.y = (rowok && col + 1 < klimit) ? v.y : 0.f;
+      v.z = (rowok && col + 2 < klimit) ? v.z : 0.f; v.w = (rowok && col + 3 < klimit) ? v.w : 0.f;
+      wr[p] = v;
+    }
+  };
+  auto wstore = [&](const f32x4 (&wr)[NW], float* buf) {
+#pragma unroll
+    for (int p = 0; p < NW; ++p) *reinterpret_cast<f32x4*>(buf + (p * RPP + wr0) * LDSW + wc4 * 4) = wr[p];
+  };
+
+  // table row of tile row (lane & 31), clamped so the load is always legal
+  const int last_tile = num_tiles - 1;
+  auto load_idx = [&](int tile, int s) -> int {
+    const int tc = tile < last_tile ? tile : last_tile;
+    int r = (tc * WAVES + wave) * RPW + (lane & 31);
+    r = r < rows ? r : rows - 1;
+    const int32_t* ip = d.seg[s].index;
+    return ip ? ip[r] : r;
+  };
+  auto load_rows = [&](f32x4 (&pre)[NP], int s, int c0, int idxv) {
+    const float* base = d.seg[s].ptr;
+    const int ld = d.seg[s].ld;
+    const int col = c0 + c4 * 4 < ld ? c0 + c4 * 4 : 0;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int tr = __shfl(idxv, p * 4 + rs, 64);
+      pre[p] = *reinterpret_cast<const f32x4*>(base + (int64_t)tr * ld + col);
+    }
+  };
+  auto stage = [&](const f32x4 (&pre)[NP], int c0, int width) {
+    compiler_lds_barrier();
+    const int c = c0 + c4 * 4;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      f32x4 v = pre[p];
+      v.x = c + 0 < width ? v.x : 0.f; v.y = c + 1 < width ? v.y : 0.f;
+      v.z = c + 2 < width ? v.z : 0.f; v.w = c + 3 < width ? v.w : 0.f;
+      *reinterpret_cast<f32x4*>(abuf + (p * 4 + rs) * LDSW + c4 * 4) = v;
+    }
+    compiler_lds_barrier();
+  };
+
+  // gather ids per segment: ids[s] = ids of the tile whose rows are requested next, ids_next[s] = the
+  // tile after that (fetched a whole tile before they are needed)
+  int ids[GNC_MAX_SEGMENTS], ids_next[GNC_MAX_SEGMENTS];
+  int tile = blockIdx.x;
+#pragma unroll
+  for (int s = 0; s < GNC_MAX_SEGMENTS; ++s) {
+    ids[s] = s < d.num_segments ? load_idx(tile, s) : 0;
+    ids_next[s] = s < d.num_segments ? load_idx(tile + (int)gridDim.x, s) : 0;
+  }
+
+  f32x4 cur[NP], cur2[NP];  // rows of the next step to stage (cur2: second segment of a combined ADD)
+  {
+    const int s0 = pl.step[0].seg;
+    int idv = 0;
+#pragma unroll
+    for (int s = 0; s < GNC_MAX_SEGMENTS; ++s) idv = s == s0 ? ids[s] : idv;
+    load_rows(cur, s0, pl.step[0].c0, idv);
+    if (ADD2 && pl.step[0].seg2 >= 0) {
+      const int s2 = pl.step[0].seg2;
+#pragma unroll
+      for (int s = 0; s < GNC_MAX_SEGMENTS; ++s) idv = s == s2 ? ids[s] : idv;
+      load_rows(cur2, s2, pl.step[0].c0, idv);
+    }
+  }
+  // weight chunk 0 -> buffer 0
+  f32x4 wreg[NW];
+  wload(wreg, 0);
+  wstore(wreg, wbuf);
+  __syncthreads();
+  int gq = 0;  // running chunk counter: chunk q of any tile sits in buffer gq & 1
+
+  // next-chunk bookkeeping shared by every weight-consuming stage
+  auto prefetch_next_chunk = [&](int q) {  // q = chunk being computed (index within the tile)
+    const int nq = q + 1 < pl.num_wchunks ? q + 1 : 0;
+    wload(wreg, nq);
+  };
+  auto publish_next_chunk = [&]() {
+    if constexpr (DBUF) {
+      wstore(wreg, wbuf + ((gq + 1) & 1) * CH);
+      __syncthreads();
+      ++gq;
+    } else {
+      __syncthreads();  // everyone is done reading the single buffer
+      wstore(wreg, wbuf);
+      __syncthreads();
+    }
+  };
+
+  while (tile < num_tiles) {
+    const int row0 = (tile * WAVES + wave) * RPW;
+    const int ntile = tile + gridDim.x;
+    int q = 0;
+
+    // ------------------------------------------------------------------ first Linear
+    f32x16 hid[HT];
+    f32x16 acc2[WT];  // second accumulator set: next hidden layer, then the output layer
+    init_bias<HT>(hid, pbuf, h);
+    for (int st = 0; st < pl.num_steps; ++st) {
+      const int s = pl.step[st].seg, s2 = pl.step[st].seg2, c0 = pl.step[st].c0;
+      const bool additive = pl.step[st].add != 0;
+      const int width = d.seg[s].width;
+      if (ADD2 && s2 >= 0) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) cur[p] += cur2[p];
+      }
+      stage(cur, c0, width);
+      // request the next step's rows (this tile, or the first step of the next tile)
+      {
+        const bool wrap = st + 1 >= pl.num_steps;
+        const int nst = wrap ? 0 : st + 1;
+        const int ns = pl.step[nst].seg, ns2 = pl.step[nst].seg2, nc0 = pl.step[nst].c0;
+        if (wrap) {  // all of this tile's gathers are out: move on to the next tile's ids
+#pragma unroll
+          for (int k = 0; k < GNC_MAX_SEGMENTS; ++k) {
+            ids[k] = ids_next[k];
+            if (k < d.num_segments) ids_next[k] = load_idx(ntile + (int)gridDim.x, k);
+          }
+        }
+        int idv = 0;
+#pragma unroll
+        for (int k = 0; k < GNC_MAX_SEGMENTS; ++k) idv = k == ns ? ids[k] : idv;
+        load_rows(cur, ns, nc0, idv);
+        if (ADD2 && ns2 >= 0) {
+#pragma unroll
+          for (int k = 0; k < GNC_MAX_SEGMENTS; ++k) idv = k == ns2 ? ids[k] : idv;
+          load_rows(cur2, ns2, nc0, idv);
+        }
+      }
+      if (additive) {
+        switch (c0 >> 6) {  // wave-uniform: keeps the accumulator index static
+          case 0: add_chunk_from_lds<HT, 0>(hid, abuf, i, h); break;
+          case 1: add_chunk_from_lds<HT, 2>(hid, abuf, i, h); break;
+          case 2: add_chunk_from_lds<HT, 4>(hid, abuf, i, h); break;
+          default: add_chunk_from_lds<HT, 6>(hid, abuf, i, h); break;
+        }
+      } else {
+        prefetch_next_chunk(q);
+        const int kc = width - c0 < KC ? width - c0 : KC;
+        mma_chunk_from_lds<HT>(hid, abuf, wbuf + (DBUF ? (gq & 1) : 0) * CH, (kc + 7) >> 3, i, h);
+        publish_next_chunk();
+        ++q;
+      }
+    }
+
+    if (L == 1) {
+      if (d.ln_gamma) layer_norm_tiles<HT>(hid, pbuf + L * PSTRIDE, pbuf + (L + 1) * PSTRIDE, out_dim, d.ln_eps, h);
+    } else {
+      relu_tiles<HT>(hid);
+      // ---------------------------------------------------------------- hidden layers 1 .. L-2
+      for (int l = 1; l < L - 1; ++l) {
+        f32x16 (&nxt)[HT] = reinterpret_cast<f32x16 (&)[HT]>(acc2);
+        init_bias<HT>(nxt, pbuf + l * PSTRIDE, h);
+#pragma unroll
+        for (int c = 0; c < (HT + 1) / 2; ++c) {
+          if (c * KC < d.in_dim[l]) {
+            prefetch_next_chunk(q);
+            mma_chunk_from_regs<HT, HT>(nxt, hid, wbuf + (DBUF ? (gq & 1) : 0) * CH, c, d.in_dim[l], i, h);
+            publish_next_chunk();
+            ++q;
+          }
+        }
+        relu_tiles<HT>(nxt);
+#pragma unroll
+        for (int t = 0; t < HT; ++t) hid[t] = nxt[t];
+      }
+    }
+
+    // ------------------------------------------------------------------ last Linear, LayerNorm, epilogue
+    f32x16 (&o)[OT] = reinterpret_cast<f32x16 (&)[OT]>(acc2);
+    if (L > 1) {
+      init_bias<OT>(o, pbuf + (L - 1) * PSTRIDE, h);
+#pragma unroll
+      for (int c = 0; c < (HT + 1) / 2; ++c) {
+        if (c * KC < d.in_dim[L - 1]) {
+          prefetch_next_chunk(q);
+          mma_chunk_from_regs<HT, OT>(o, hid, wbuf + (DBUF ? (gq & 1) : 0) * CH, c, d.in_dim[L - 1], i, h);
+          publish_next_chunk();
+          ++q;
+        }
+      }
+      if (d.ln_gamma) layer_norm_tiles<OT>(o, pbuf + L * PSTRIDE, pbuf + (L + 1) * PSTRIDE, out_dim, d.ln_eps, h);
+    } else {
+      if constexpr (OT == HT) {
+#pragma unroll
+        for (int t = 0; t < OT; ++t) o[t] = hid[t];
+      }
+    }
+
+    // collect the next tile's prefetched rows before the asm stores join the memory queue
+#pragma unroll
+    for (int p = 0; p < NP; ++p) asm volatile("" ::"v"(cur[p]));
+
+    constexpr int OCH = (OT + 1) / 2;
+#pragma unroll
+    for (int cc = 0; cc < OCH; ++cc) {
+      if (cc * KC < out_dim) {
+        compiler_lds_barrier();
+        switch (cc) {  // compile-time after unrolling; keeps the accumulator index static
+          case 0: chunk_to_lds<OT, 0>(o, abuf, i, h); break;
+          case 1: chunk_to_lds<OT, 2>(o, abuf, i, h); break;
+          case 2: chunk_to_lds<OT, 4>(o, abuf, i, h); break;
+          default: chunk_to_lds<OT, 6>(o, abuf, i, h); break;
+        }
+        compiler_lds_barrier();
+        const int col = cc * KC + c4 * 4;
+        const bool col_ok = col < out_dim;
+        const int colc = col_ok ? col : 0;
+        const bool vec_out = (out_dim % 4 == 0) && (d.ld_out % 4 == 0) && ((reinterpret_cast<uintptr_t>(d.out) & 15u) == 0);
+        f32x4 (&outv)[NP] = cur2;  // free here: a tile always starts with a MATMUL step, which uses `cur` only
+#pragma unroll
+        for (int p = 0; p < NP; ++p) outv[p] = *reinterpret_cast<const f32x4*>(abuf + (p * 4 + rs) * LDSW + c4 * 4);
+        if (d.residual) {  // rows this tile read a moment ago (L2 hits); unconditional, clamped
+          const int rc = colc < d.ld_residual ? colc : 0;
+#pragma unroll
+          for (int p = 0; p < NP; ++p) {
+            int r = row0 + p * 4 + rs;
+            r = r < rows ? r : rows - 1;
+            outv[p] += *reinterpret_cast<const f32x4*>(d.residual + (int64_t)r * d.ld_residual + rc);
+          }
+        }
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const int r = row0 + p * 4 + rs;
+          store_row_piece(d.out + (int64_t)(r < rows ? r : rows - 1) * d.ld_out, col, outv[p], r < rows && col_ok,
+                          out_dim, vec_out);
+        }
+      }
+    }
+    compiler_lds_barrier();
+    tile = ntile;
+  }
+}
+
+template <int HT, int OT, int WAVES, bool DBUF, bool ADD2>
+int launch(const gnc_mlp_desc_t& d, const StreamPlan& pl, hipStream_t stream) {
+  constexpr int WT = HT > OT ? HT : OT;
+  const size_t smem =
+      ((size_t)(DBUF ? 2 : 1) * WT * 32 * LDSW + (size_t)(d.num_linear + 2) * WT * 32 + (size_t)WAVES * RPW * LDSW) * sizeof(float);
+  if (smem > 160 * 1024) {
+    gnc::set_error("mlp_stream: LDS budget exceeded (%zu bytes)", smem);
+    return GNC_ERR_UNSUPPORTED;
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    int rc = gnc::check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_stream_kernel<HT, OT, WAVES, DBUF, ADD2>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                            "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    if (rc) return rc;
+    attr_set = true;
+  }
+  const int64_t num_tiles = gnc::ceil_div(d.rows, (int64_t)WAVES * RPW);
+  int64_t grid = num_tiles < gnc::kNumCU ? num_tiles : gnc::kNumCU;  // one persistent workgroup per CU
+  mlp_stream_kernel<HT, OT, WAVES, DBUF, ADD2><<<dim3((unsigned)grid), dim3(WAVES * 64), smem, stream>>>(d, pl, (int)num_tiles);
+  return gnc::check_launch("mlp_stream_kernel");
+}
+
+bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+
+int gnc_mlp::launch_stream(const gnc_mlp_desc_t& d, int T, bool narrow_out, hipStream_t stream, bool* launched) {
+  *launched = false;
+  static const bool disabled = getenv("GNC_MLP_NO_STREAM2") != nullptr;  // A/B switch for benchmarking
+  if (disabled || d.rows >= INT32_MAX) return GNC_OK;
+  const int L = d.num_linear;
+  if (L > 1 && d.activation != GNC_ACT_RELU) return GNC_OK;
+  if (d.residual && (d.ld_residual % 4 != 0 || !al16(d.residual))) return GNC_OK;
+  for (int l = 0; l < L; ++l)
+    if (ldw_of(d, l) % 4 != 0 || !al16(d.weight[l])) return GNC_OK;
+
+  StreamPlan pl = {};
+  // steps: MATMUL segments in listed order, then the additive ones (pairs merged)
+  int add_seg[GNC_MAX_SEGMENTS], nadd = 0;
+  for (int s = 0; s < d.num_segments; ++s) {
+    const gnc_mlp_segment_t& g = d.seg[s];
+    if (g.ld % 4 != 0 || !al16(g.ptr)) return GNC_OK;
+    if (g.mode == GNC_SEG_ADD) { add_seg[nadd++] = s; continue; }
+    if (g.wcol % 4 != 0) return GNC_OK;
+    for (int c0 = 0; c0 < g.width; c0 += KC) {
+      if (pl.num_steps >= MAX_STEPS || pl.num_wchunks >= MAX_WCHUNKS) return GNC_OK;
+      pl.step[pl.num_steps++] = {(short)s, (short)-1, (short)c0, (short)0};
+      const int kl = g.wcol + g.width;
+      pl.wc[pl.num_wchunks++] = {(short)0, (short)(g.wcol + c0), (short)kl, 0};
+    }
+  }
+  if (pl.num_wchunks == 0) return GNC_OK;
+  const int pair = T < 8 ? 2 : 1;  // the 256-wide instance stages additive segments one by one
+  for (int a = 0; a < nadd; a += pair) {
+    const int s = add_seg[a], s2 = (pair == 2 && a + 1 < nadd) ? add_seg[a + 1] : -1;
+    for (int c0 = 0; c0 < d.seg[s].width; c0 += KC) {
+      if (pl.num_steps >= MAX_STEPS) return GNC_OK;
+      pl.step[pl.num_steps++] = {(short)s, (short)s2, (short)c0, (short)1};
+    }
+  }
+  for (int l = 1; l < L; ++l)
+    for (int c = 0; c * KC < d.in_dim[l]; ++c) {
+      if (pl.num_wchunks >= MAX_WCHUNKS) return GNC_OK;
+      pl.wc[pl.num_wchunks++] = {(short)l, (short)(c * KC), (short)d.in_dim[l], 0};
+    }
+
+  *launched = true;
+  if (narrow_out) {  // out width <= 32 (the decoder): one output tile
+    switch (T) {
+      case 1: return launch<1, 1, 8, true, true>(d, pl, stream);
+      case 2: return launch<2, 1, 8, true, true>(d, pl, stream);
+      case 4: return launch<4, 1, 4, true, true>(d, pl, stream);
+      default: return launch<8, 1, 4, false, false>(d, pl, stream);
+    }
+  }
+  switch (T) {
+    case 1: return launch<1, 1, 8, true, true>(d, pl, stream);
+    case 2: return launch<2, 2, 8, true, true>(d, pl, stream);
+    case 4: return launch<4, 4, 4, true, true>(d, pl, stream);
+    default: return launch<8, 8, 4, false, false>(d, pl, stream);
+  }
+}

@@ -282,6 +282,31 @@ def make_mlp_desc(segments, weights, biases, ln, activation: str, act_param: flo
 
 SEG_MATMUL, SEG_ADD = 0, 1
 
+_padded_cache: dict = {}
+
+
+def _vector_rows(t: torch.Tensor, cache: bool = False) -> torch.Tensor:
+    """Rows the kernels can read with 16-B vector loads: row stride a multiple of 4 floats and a 16-B
+    aligned base.  Anything else (the reference's 3-column inputs and [H, 3] first-layer weights) is
+    copied once into a zero-padded buffer and handed over as a column slice of it; small weights are
+    cached by identity and version (an optimizer step bumps the version)."""
+    if t.data_ptr() % 16 == 0 and (t.size(0) <= 1 or t.stride(0) % 4 == 0):
+        return t
+    key = (t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride())) if cache else None
+    if key is not None and key in _padded_cache:
+        return _padded_cache[key][0]
+    cols = (t.size(1) + 3) // 4 * 4
+    buf = torch.zeros(t.size(0), cols, dtype=t.dtype, device=t.device)
+    buf[:, :t.size(1)] = t
+    view = buf[:, :t.size(1)]
+    if key is not None:
+        if len(_padded_cache) > 256:
+            _padded_cache.clear()
+        _padded_cache[key] = (view, t)  # keeps `t` alive so its address cannot be recycled under the key
+    return view
+
+
+
 
 def mlp_forward(segments, weights, biases, ln=None, activation: str = "ReLU", act_param: float = 0.0,
                 residual: torch.Tensor | None = None, rows: int | None = None, modes=None) -> torch.Tensor:
@@ -294,7 +319,7 @@ def mlp_forward(segments, weights, biases, ln=None, activation: str = "ReLU", ac
     segs, wcol = [], 0
     for (table, index), mode in zip(segments, modes):
         _require_cuda(table, index)
-        table = _rowmajor(table)
+        table = _vector_rows(_rowmajor(table))
         if index is not None and index.dtype != torch.int32:
             raise TypeError("segment index must be int32")
         segs.append((table, index, table.size(1), mode, wcol if mode == SEG_MATMUL else 0))
@@ -310,7 +335,7 @@ def mlp_forward(segments, weights, biases, ln=None, activation: str = "ReLU", ac
     if rows is None:
         t0, i0 = segments[0]
         rows = i0.numel() if i0 is not None else t0.size(0)
-    weights = [_rowmajor(w) for w in weights]
+    weights = [_vector_rows(_rowmajor(w.detach()), cache=True) for w in weights]
     biases = [b.contiguous() if b is not None else None for b in biases]
     dev = segs[0][0].device
     out = torch.empty(rows, weights[-1].size(0), dtype=torch.float32, device=dev)
