@@ -122,7 +122,7 @@ __device__ __forceinline__ void init_bias(f32x16 (&acc)[T], const float* pb, int
 template <int T>
 __device__ __forceinline__ void mma_chunk_from_lds(f32x16 (&acc)[T], const float* abuf, const float* wbuf, int kc8,
                                                    int i, int h) {
-#pragma unroll 2
+#pragma unroll(T >= 4 ? 1 : 2)
   for (int g = 0; g < kc8; ++g) {
     const f32x4 b = *reinterpret_cast<const f32x4*>(abuf + i * LDSW + 8 * g + 4 * h);
 #pragma unroll

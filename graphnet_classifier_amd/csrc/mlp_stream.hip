@@ -408,7 +408,7 @@ int gnc_mlp::launch_stream(const gnc_mlp_desc_t& d, int T, bool narrow_out, hipS
     }
   }
   if (pl.num_wchunks == 0) return GNC_OK;
-  const int pair = T < 8 ? 2 : 1;  // the 256-wide instance stages additive segments one by one
+  const int pair = T < 4 ? 2 : 1;  // the 128/256-wide instances stage additive segments one by one
   for (int a = 0; a < nadd; a += pair) {
     const int s = add_seg[a], s2 = (pair == 2 && a + 1 < nadd) ? add_seg[a + 1] : -1;
     for (int c0 = 0; c0 < d.seg[s].width; c0 += KC) {
@@ -434,7 +434,10 @@ int gnc_mlp::launch_stream(const gnc_mlp_desc_t& d, int T, bool narrow_out, hipS
   switch (T) {
     case 1: return launch<1, 1, 8, true, true>(d, pl, stream);
     case 2: return launch<2, 2, 8, true, true>(d, pl, stream);
-    case 4: return launch<4, 4, 4, true, true>(d, pl, stream);
+    case 4: {
+      static const bool w4 = getenv("GNC_STREAM_W4") != nullptr;  // A/B: 4 waves x 512 registers instead of 8 x 256
+      return w4 ? launch<4, 4, 4, true, false>(d, pl, stream) : launch<4, 4, 8, true, false>(d, pl, stream);
+    }
     default: return launch<8, 8, 4, false, false>(d, pl, stream);
   }
 }
