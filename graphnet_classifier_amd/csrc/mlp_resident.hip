@@ -43,7 +43,7 @@ constexpr int RNT = RWAVES * 64;
 // the LAST MATMUL step (no index): its rows are kept in registers instead of being re-read.
 template <int HT, int OT, int NMM, int NADD, bool RESREG>
 __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t d, const int num_wtiles,
-                                                           const int total_chunks) {
+                                                           const int total_chunks, const int flags) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int WT = HT > OT ? HT : OT;
   constexpr int CH = WT * 32 * LDSW;  // floats per resident weight chunk
@@ -89,6 +89,7 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
   // ---- per-wave pipeline -----------------------------------------------------------------------
   const int total_waves = (int)gridDim.x * RWAVES;
   const int last_wt = num_wtiles - 1;
+  const bool NT_STREAM = (flags & 1) != 0;
 
   // table row of tile row (lane & 31); clamped so the load is always legal
   auto load_idx = [&](int wt, const SegView& s) -> int {
@@ -100,10 +101,18 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
   // the step's rows: lane (rs, c4) gets 16 B of row p*4+rs for p = 0..7; no predication
   auto load_rows = [&](f32x4 (&pre)[NP], const SegView& s, int idxv) {
     const int col = c4 * 4 < s.ld ? c4 * 4 : 0;
+    if (s.index == nullptr && NT_STREAM) {  // rows read once, in order: keep them out of L2 / MALL
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      const int tr = __shfl(idxv, p * 4 + rs, 64);
-      pre[p] = *reinterpret_cast<const f32x4*>(s.ptr + (int64_t)tr * s.ld + col);
+      for (int p = 0; p < NP; ++p) {
+        const int tr = __shfl(idxv, p * 4 + rs, 64);
+        pre[p] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(s.ptr + (int64_t)tr * s.ld + col));
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int tr = __shfl(idxv, p * 4 + rs, 64);
+        pre[p] = *reinterpret_cast<const f32x4*>(s.ptr + (int64_t)tr * s.ld + col);
+      }
     }
   };
   // registers -> the wave's LDS tile; columns at or beyond the segment width become zero
@@ -253,8 +262,9 @@ int launch(const gnc_mlp_desc_t& d, int total_chunks, size_t smem, hipStream_t s
   const int64_t num_wtiles = gnc::ceil_div(d.rows, RPW);
   int64_t grid = gnc::ceil_div(num_wtiles, RWAVES);
   if (grid > gnc::kNumCU) grid = gnc::kNumCU;  // one persistent workgroup per CU
+  static const int flags = getenv("GNC_MLP_NT") ? atoi(getenv("GNC_MLP_NT")) : 0;  // bit 0: nontemporal streamed rows
   mlp_resident_kernel<HT, OT, NMM, NADD, RESREG>
-      <<<dim3((unsigned)grid), dim3(RNT), smem, stream>>>(d, (int)num_wtiles, total_chunks);
+      <<<dim3((unsigned)grid), dim3(RNT), smem, stream>>>(d, (int)num_wtiles, total_chunks, flags);
   return gnc::check_launch("mlp_resident_kernel");
 }
 

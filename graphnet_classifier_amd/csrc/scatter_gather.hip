@@ -18,6 +18,13 @@ using gnc::kWave;
 struct alignas(16) f4 { float x, y, z, w; };
 
 __device__ __forceinline__ f4 ld4(const float* p) { return *reinterpret_cast<const f4*>(p); }
+// Streamed-once rows (the messages of K1): nontemporal 16-B load, so the 2.5 GB stream does not push the
+// row pointers / output lines out of L2 and MALL.  Measured at c3 size: 0.592 -> 0.529 ms per launch.
+__device__ __forceinline__ f4 ld4_stream(const float* p) {
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  const v4 v = __builtin_nontemporal_load(reinterpret_cast<const v4*>(p));
+  return f4{v.x, v.y, v.z, v.w};
+}
 __device__ __forceinline__ void st4(float* p, f4 v) { *reinterpret_cast<f4*>(p) = v; }
 __device__ __forceinline__ void acc4(f4& a, const f4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
 
@@ -65,15 +72,15 @@ __global__ __launch_bounds__(gnc::kBlock) void scatter_sum_csr_vec4(
         for (; k + 4 <= end; k += 4) {
           int32_t i0 = k, i1 = k + 1, i2 = k + 2, i3 = k + 3;
           if (HAS_PERM) { i0 = perm[k]; i1 = perm[k + 1]; i2 = perm[k + 2]; i3 = perm[k + 3]; }
-          const f4 r0 = ld4(src + (int64_t)i0 * ld_src + col);
-          const f4 r1 = ld4(src + (int64_t)i1 * ld_src + col);
-          const f4 r2 = ld4(src + (int64_t)i2 * ld_src + col);
-          const f4 r3 = ld4(src + (int64_t)i3 * ld_src + col);
+          const f4 r0 = ld4_stream(src + (int64_t)i0 * ld_src + col);
+          const f4 r1 = ld4_stream(src + (int64_t)i1 * ld_src + col);
+          const f4 r2 = ld4_stream(src + (int64_t)i2 * ld_src + col);
+          const f4 r3 = ld4_stream(src + (int64_t)i3 * ld_src + col);
           acc4(a, r0); acc4(a, r1); acc4(a, r2); acc4(a, r3);  // ascending k: reference edge order
         }
         for (; k < end; ++k) {
           const int32_t i0 = HAS_PERM ? perm[k] : k;
-          acc4(a, ld4(src + (int64_t)i0 * ld_src + col));
+          acc4(a, ld4_stream(src + (int64_t)i0 * ld_src + col));
         }
         st4(out + v * ld_out + col, a);
       }
