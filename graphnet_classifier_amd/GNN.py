@@ -78,7 +78,7 @@ class EdgeProcessor(nn.Module):
                 and lin[0].in_features == 2 * x.size(1) + edge_attr.size(1) and x.size(1) % 4 == 0):
             # W-split of the first Linear: node-side products once per node, gathered and added per edge
             ln = (norm.weight, norm.bias, norm.eps) if isinstance(norm, nn.LayerNorm) else None
-            return Fn.edge_processor_wsplit(x, edge_attr, topo.src_sorted, topo.dst_sorted, [m.weight for m in lin],
+            return Fn.edge_processor_wsplit(x, edge_attr, topo, [m.weight for m in lin],
                                             [m.bias for m in lin], ln, mlp.activation_name, mlp._act_param())
         return mlp.forward_segments(
             [(x, topo.src_sorted), (x, topo.dst_sorted), (edge_attr, None)], residual=edge_attr, rows=topo.num_edges)

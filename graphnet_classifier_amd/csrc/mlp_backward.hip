@@ -1,0 +1,589 @@
+// Backward of the fused MLP (K8 of SURVEY.md section 2.2: the autograd of K4), split in two kernels.
+//
+// The reference's caller that needs it is utils/train_model.py:41 (`loss.backward()`): PyTorch's autograd
+// through models/MLP.py:45-47 and the concat / residual around it (models/GNN.py:58-62, :100-102).
+//
+// mlp_backward_data_kernel  (one launch per MLP call, same tiling as the weights-resident forward):
+//   recomputes the forward of its 32-row tile on the fp32 MFMA path (nothing was saved by the forward
+//   but its inputs), then walks the chain backwards with the SAME resident weight chunks read
+//   transposed (ds_read_b32 down a column):
+//        g            -> LayerNorm backward -> dy            (and per-wave partial sums of d gamma, d beta)
+//        da_l = W_{l+1}^T dz_{l+1},  dz_l = da_l * (a_l > 0)   for l = L-2 .. 0   (ReLU masks: 1 bit per value)
+//        dx   = W_0^T dz_0                                     (grad of the MATMUL part of the input concat)
+//   The accumulator layout keeps the feature index in the register and the data row on the lane in both
+//   directions, so dz_{l+1} is the B operand of the next product as it stands.  It writes what the weight
+//   gradients need: a_l (layer inputs) and dz_l, as whole 256-B rows.
+// xty_kernel  (one launch per Linear): dW = dz^T a and db = colsum(dz): a row-streaming skinny GEMM,
+//   rows on the MFMA k axis, per-wave partial results (summed afterwards in a fixed order, so weight
+//   gradients are bitwise reproducible; no atomics).
+#include <stdlib.h>
+
+#include "mlp_device.h"
+
+using namespace gnc_mlp;
+
+namespace {
+
+constexpr int BWAVES = 8;
+constexpr int BNT = BWAVES * 64;
+
+// dst[t'] += W^T-tile * src: contraction over the feature index n of src (register r of tile t holds
+// n = 32t + (r&3) + 8(r>>2) + 4h); A operand = W[n][32t' + i] read down the column of the [n][k] chunk.
+template <int TI, int TO>
+__device__ __forceinline__ void mma_transposed_from_regs(f32x16 (&dst)[TO], const f32x16 (&src)[TI], const float* wbuf,
+                                                         int i, int h) {
+#pragma unroll
+  for (int t = 0; t < TI; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+#pragma unroll
+      for (int tp = 0; tp < TO; ++tp) {
+        const float a = wbuf[n * LDSW + 32 * tp + i];
+        dst[tp] = mfma(a, src[t][r], dst[tp]);
+      }
+    }
+}
+
+template <int T>
+__device__ __forceinline__ void zero_tiles(f32x16 (&acc)[T]) {
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+}
+
+// bit (16t + r) = acc[t][r] > 0 (T <= 2); ReLU applied in place
+template <int T>
+__device__ __forceinline__ unsigned relu_tiles_mask(f32x16 (&acc)[T]) {
+  unsigned m = 0;
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const bool pos = acc[t][r] > 0.f;
+      m |= pos ? (1u << (16 * t + r)) : 0u;
+      acc[t][r] = pos ? acc[t][r] : 0.f;
+    }
+  return m;
+}
+
+template <int T>
+__device__ __forceinline__ void apply_mask(f32x16 (&acc)[T], unsigned m) {
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = (m >> (16 * t + r)) & 1u ? acc[t][r] : 0.f;
+}
+
+template <int T>
+__device__ __forceinline__ void tile_from_lds(f32x16 (&acc)[T], const float* abuf, int i, int h) {
+#pragma unroll
+  for (int t = 0; t < T && t < 2; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(abuf + i * LDSW + 32 * t + 8 * q + 4 * h);
+      acc[t][4 * q + 0] = v.x; acc[t][4 * q + 1] = v.y; acc[t][4 * q + 2] = v.z; acc[t][4 * q + 3] = v.w;
+    }
+}
+
+struct BwdArgs {
+  const float* grad_out;
+  int ld_grad_out;
+  float* act[GNC_MAX_LINEAR];  // [rows, H] post-activation outputs of layers 0 .. L-2
+  float* dz[GNC_MAX_LINEAR];   // [rows, width_l] grad wrt the pre-activation of layer l (l = L-1: pre-LayerNorm)
+  float* dx;                   // nullable: [rows, in_dim0] grad wrt the MATMUL part of the input
+  int ld_dx;
+  float* yhat;                 // [rows, out_dim] normalised pre-affine output (only with LayerNorm)
+};
+
+// HT = tiles of the hidden AND output width (both <= 64).  NMM / NADD as in mlp_resident.hip.
+template <int HT, int NMM, int NADD>
+__global__ __launch_bounds__(BNT) void mlp_backward_data_kernel(const gnc_mlp_desc_t d, const BwdArgs b,
+                                                                const int num_wtiles, const int total_chunks) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int CH = HT * 32 * LDSW;
+  constexpr int PSTRIDE = HT * 32;
+  constexpr int NS = NMM + NADD;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 31;
+  const int h = lane >> 5;
+  const int c4 = lane & 15;
+  const int rs = lane >> 4;
+  const int L = d.num_linear;
+  const int out_dim = d.out_dim[L - 1];
+  const int rows = (int)d.rows;
+  float* wres = lds;
+  float* pbuf = lds + total_chunks * CH;
+  float* abuf = pbuf + (L + 2) * PSTRIDE + wave * RPW * LDSW;
+
+  stage_params<BNT>(pbuf, d, PSTRIDE, tid);
+  {
+    int chunk = 0;
+    const int ldw0 = ldw_of(d, 0);
+    const bool w0v = (ldw0 % 4 == 0) && ((reinterpret_cast<uintptr_t>(d.weight[0]) & 15u) == 0);
+#pragma unroll
+    for (int s = 0; s < NMM; ++s, ++chunk)
+      stage_weights<HT * 32, BNT>(wres + chunk * CH, d.weight[0], ldw0, d.out_dim[0], d.seg[s].wcol,
+                                  d.seg[s].wcol + d.seg[s].width, 16, w0v && (d.seg[s].wcol % 4 == 0), tid);
+    for (int l = 1; l < L; ++l) {
+      const int ldw = ldw_of(d, l);
+      const bool wv = (ldw % 4 == 0) && ((reinterpret_cast<uintptr_t>(d.weight[l]) & 15u) == 0);
+      stage_weights<HT * 32, BNT>(wres + chunk * CH, d.weight[l], ldw, d.out_dim[l], 0, d.in_dim[l], 16, wv, tid);
+      ++chunk;
+    }
+  }
+  __syncthreads();
+
+  SegView sv[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) sv[s] = {d.seg[s].ptr, d.seg[s].index, d.seg[s].ld, d.seg[s].width};
+
+  const int total_waves = (int)gridDim.x * BWAVES;
+  const int last_wt = num_wtiles - 1;
+
+  auto load_idx = [&](int wt, const SegView& s) -> int {
+    const int wtc = wt < last_wt ? wt : last_wt;
+    int r = wtc * RPW + (lane & 31);
+    r = r < rows ? r : rows - 1;
+    return s.index ? s.index[r] : r;
+  };
+  auto load_rows = [&](f32x4 (&pre)[NP], const float* base, int ld, int idxv) {
+    const int col = c4 * 4 < ld ? c4 * 4 : 0;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int tr = __shfl(idxv, p * 4 + rs, 64);
+      pre[p] = *reinterpret_cast<const f32x4*>(base + (int64_t)tr * ld + col);
+    }
+  };
+  auto stage = [&](const f32x4 (&pre)[NP], int width) {
+    compiler_lds_barrier();
+    const int c = c4 * 4;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      f32x4 v = pre[p];
+      v.x = c + 0 < width ? v.x : 0.f; v.y = c + 1 < width ? v.y : 0.f;
+      v.z = c + 2 < width ? v.z : 0.f; v.w = c + 3 < width ? v.w : 0.f;
+      *reinterpret_cast<f32x4*>(abuf + (p * 4 + rs) * LDSW + c) = v;
+    }
+    compiler_lds_barrier();
+  };
+  // accumulator tiles -> whole rows of a [rows, ld] tensor (columns < width), through the wave's LDS tile
+  auto emit = [&](const f32x16 (&acc)[HT], float* dst, int ld, int width, int row0) {
+    compiler_lds_barrier();
+    tiles_to_lds<HT>(acc, abuf, i, h);
+    compiler_lds_barrier();
+    const int col = c4 * 4;
+    const bool vec = (width % 4 == 0) && (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int r = row0 + p * 4 + rs;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(abuf + (p * 4 + rs) * LDSW + col);
+      store_row_piece(dst + (int64_t)(r < rows ? r : rows - 1) * ld, col, v, r < rows && col < width, width, vec);
+    }
+    compiler_lds_barrier();
+  };
+
+  for (int wt = (int)blockIdx.x * BWAVES + wave; wt < num_wtiles; wt += total_waves) {
+    const int row0 = wt * RPW;
+
+    // ------------------------------------------------------------------ forward recompute
+    f32x16 hid[HT];
+    init_bias<HT>(hid, pbuf, h);
+    {
+      f32x4 pre[NP], pre2[NP];
+#pragma unroll
+      for (int s = 0; s < NMM; ++s) {
+        load_rows(pre, sv[s].ptr, sv[s].ld, load_idx(wt, sv[s]));
+        stage(pre, sv[s].width);
+        mma_chunk_from_lds<HT>(hid, abuf, wres + s * CH, (sv[s].width + 7) >> 3, i, h);
+      }
+      if constexpr (NADD > 0) {
+        load_rows(pre, sv[NMM].ptr, sv[NMM].ld, load_idx(wt, sv[NMM]));
+        load_rows(pre2, sv[NMM + 1].ptr, sv[NMM + 1].ld, load_idx(wt, sv[NMM + 1]));
+#pragma unroll
+        for (int p = 0; p < NP; ++p) pre[p] += pre2[p];
+        stage(pre, sv[NMM].width);
+        add_tile_from_lds<HT>(hid, abuf, i, h);
+      }
+    }
+    unsigned mask[GNC_MAX_LINEAR - 1];
+    mask[0] = relu_tiles_mask<HT>(hid);
+    emit(hid, b.act[0], d.out_dim[0], d.out_dim[0], row0);
+#pragma unroll
+    for (int l = 1; l < GNC_MAX_LINEAR - 1; ++l) {
+      if (l < L - 1) {
+        f32x16 nxt[HT];
+        init_bias<HT>(nxt, pbuf + l * PSTRIDE, h);
+        mma_chunk_from_regs<HT, HT>(nxt, hid, wres + (NMM + l - 1) * CH, 0, d.in_dim[l], i, h);
+        mask[l] = relu_tiles_mask<HT>(nxt);
+#pragma unroll
+        for (int t = 0; t < HT; ++t) hid[t] = nxt[t];
+        emit(hid, b.act[l], d.out_dim[l], d.out_dim[l], row0);
+      }
+    }
+
+    // ------------------------------------------------------------------ grad of the pre-LayerNorm output
+    f32x16 g[HT];
+    {
+      f32x4 pre[NP];
+      int r = row0 + (lane & 31);
+      r = r < rows ? r : rows - 1;
+      load_rows(pre, b.grad_out, b.ld_grad_out, r);
+      stage(pre, out_dim);
+      tile_from_lds<HT>(g, abuf, i, h);
+      compiler_lds_barrier();
+    }
+    if (d.ln_gamma) {
+      f32x16 y[HT];
+      init_bias<HT>(y, pbuf + (L - 1) * PSTRIDE, h);
+      mma_chunk_from_regs<HT, HT>(y, hid, wres + (NMM + L - 2) * CH, 0, d.in_dim[L - 1], i, h);
+      // statistics of the row (lane): y -> normalised y_hat
+      float s = 0.f;
+#pragma unroll
+      for (int t = 0; t < HT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += (feat_of(t, r, h) < out_dim) ? y[t][r] : 0.f;
+      s += __shfl_xor(s, 32, 64);
+      const float mean = s / (float)out_dim;
+      float v = 0.f;
+#pragma unroll
+      for (int t = 0; t < HT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float dl = y[t][r] - mean;
+          v += (feat_of(t, r, h) < out_dim) ? dl * dl : 0.f;
+        }
+      v += __shfl_xor(v, 32, 64);
+      const float rstd = 1.f / sqrtf(v / (float)out_dim + d.ln_eps);
+      const float* pg = pbuf + L * PSTRIDE;
+      float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+      for (int t = 0; t < HT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 gm = *reinterpret_cast<const f32x4*>(pg + 32 * t + 8 * q + 4 * h);
+          const float gmv[4] = {gm.x, gm.y, gm.z, gm.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int r = 4 * q + k;
+            const bool ok = feat_of(t, r, h) < out_dim;
+            const float yh = ok ? (y[t][r] - mean) * rstd : 0.f;
+            const float gv = ok ? g[t][r] : 0.f;
+            const float gg = gv * gmv[k];  // gamma is zero-padded
+            m1 += gg;
+            m2 += gg * yh;
+            y[t][r] = yh;
+            g[t][r] = gg;
+          }
+        }
+      emit(y, b.yhat, out_dim, out_dim, row0);  // normalised pre-affine output: d gamma = colsum(grad_out * yhat)
+      m1 += __shfl_xor(m1, 32, 64);
+      m2 += __shfl_xor(m2, 32, 64);
+      m1 /= (float)out_dim;
+      m2 /= (float)out_dim;
+#pragma unroll
+      for (int t = 0; t < HT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          g[t][r] = (feat_of(t, r, h) < out_dim) ? rstd * (g[t][r] - m1 - y[t][r] * m2) : 0.f;
+    } else {
+#pragma unroll
+      for (int t = 0; t < HT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[t][r] = (feat_of(t, r, h) < out_dim) ? g[t][r] : 0.f;
+    }
+    emit(g, b.dz[L - 1], out_dim, out_dim, row0);  // dy
+
+    // ------------------------------------------------------------------ back through the Linear layers
+#pragma unroll
+    for (int l = GNC_MAX_LINEAR - 2; l >= 0; --l) {
+      if (l < L - 1) {
+        f32x16 da[HT];
+        zero_tiles<HT>(da);
+        mma_transposed_from_regs<HT, HT>(da, g, wres + (NMM + l) * CH, i, h);  // W_{l+1}^T dz_{l+1}
+        apply_mask<HT>(da, mask[l]);
+#pragma unroll
+        for (int t = 0; t < HT; ++t) g[t] = da[t];
+        emit(g, b.dz[l], d.out_dim[l], d.out_dim[l], row0);
+      }
+    }
+    if (b.dx) {
+#pragma unroll
+      for (int s = 0; s < NMM; ++s) {
+        f32x16 dxs[HT];
+        zero_tiles<HT>(dxs);
+        mma_transposed_from_regs<HT, HT>(dxs, g, wres + s * CH, i, h);  // columns wcol_s .. of W_0^T dz_0
+        emit(dxs, b.dx + d.seg[s].wcol, b.ld_dx, sv[s].width, row0);
+      }
+    }
+  }
+
+}
+
+// ---------------------------------------------------------------------------------------------------
+// xty: C[M, K] = sum over rows of A[row, 0:M]^T B[row, 0:K];  colsum[M] = sum over rows of A[row, 0:M]
+// (dW = dz^T a, db = colsum(dz)).  M, K <= 64.  Each wave streams 32-row tiles with the rows on the MFMA
+// k axis (2 rows per step: lane (i, h) holds A[row 2s+h][32 tA + i] and B[row 2s+h][32 tB + i]: 128-B
+// contiguous per half-wave) and keeps its own partial C; partials are summed afterwards in a fixed order.
+// ---------------------------------------------------------------------------------------------------
+template <int TM, int TK>
+__global__ __launch_bounds__(256) void xty_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
+                                                  int64_t ldb, int rows, int M, int K, float* __restrict__ partial,
+                                                  int pstride) {
+  const int lane = threadIdx.x & 63;
+  const int i = lane & 31;
+  const int h = lane >> 5;
+  const int wave = ((int)blockIdx.x * (int)blockDim.x + (int)threadIdx.x) >> 6;
+  const int total_waves = ((int)gridDim.x * (int)blockDim.x) >> 6;
+  const int num_tiles = (rows + RPW - 1) / RPW;
+  f32x16 acc[TM][TK];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int c = 0; c < TK; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+  float csum[TM];
+#pragma unroll
+  for (int a = 0; a < TM; ++a) csum[a] = 0.f;
+  const int ia[2] = {i < M ? i : 0, 32 + i < M ? 32 + i : 0};
+  const int ib[2] = {i < K ? i : 0, 32 + i < K ? 32 + i : 0};
+  const bool oka[2] = {i < M, 32 + i < M};
+  const bool okb[2] = {i < K, 32 + i < K};
+
+  for (int tile = wave; tile < num_tiles; tile += total_waves) {
+    const int row0 = tile * RPW;
+#pragma unroll 4
+    for (int s = 0; s < RPW / 2; ++s) {
+      const int r = row0 + 2 * s + h;
+      const int rc = r < rows ? r : rows - 1;
+      float av[TM], bv[TK];
+#pragma unroll
+      for (int a = 0; a < TM; ++a) {
+        const float v = A[(int64_t)rc * lda + ia[a]];
+        av[a] = (r < rows && oka[a]) ? v : 0.f;
+        csum[a] += av[a];
+      }
+#pragma unroll
+      for (int c = 0; c < TK; ++c) {
+        const float v = B[(int64_t)rc * ldb + ib[c]];
+        bv[c] = (r < rows && okb[c]) ? v : 0.f;
+      }
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int c = 0; c < TK; ++c) acc[a][c] = mfma(av[a], bv[c], acc[a][c]);
+    }
+  }
+  // partial layout per wave: [M*K] row-major C, then [M] column sums
+  float* dst = partial + (int64_t)wave * pstride;
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int c = 0; c < TK; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int k = 32 * c + i;
+        if (m < M && k < K) dst[m * K + k] = acc[a][c][r];
+      }
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+    const float tot = csum[a] + __shfl_xor(csum[a], 32, 64);
+    if (h == 0 && 32 * a + i < M) dst[M * K + 32 * a + i] = tot;
+  }
+}
+
+// colsum_pair: partial[w] = [ column sums of G | column sums of G*Y ] over the rows wave w streamed
+// (d beta and d gamma of the LayerNorm: G = grad_out, Y = yhat).  width <= 64, 16-B aligned rows.
+__global__ __launch_bounds__(256) void colsum_pair_kernel(const float* __restrict__ G, int64_t ldg,
+                                                          const float* __restrict__ Y, int64_t ldy, int rows, int width,
+                                                          float* __restrict__ partial) {
+  const int lane = threadIdx.x & 63;
+  const int c4 = lane & 15, rs = lane >> 4;
+  const int wave = ((int)blockIdx.x * (int)blockDim.x + (int)threadIdx.x) >> 6;
+  const int total_waves = ((int)gridDim.x * (int)blockDim.x) >> 6;
+  const int col = c4 * 4 < width ? c4 * 4 : 0;
+  f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sgy = {0.f, 0.f, 0.f, 0.f};
+  for (int r0 = wave * 16; r0 < rows; r0 += total_waves * 16) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int r = r0 + p * 4 + rs;
+      const int rc = r < rows ? r : rows - 1;
+      const f32x4 g = *reinterpret_cast<const f32x4*>(G + (int64_t)rc * ldg + col);
+      const f32x4 y = *reinterpret_cast<const f32x4*>(Y + (int64_t)rc * ldy + col);
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      const f32x4 gm = r < rows ? g : z;
+      sg += gm;
+      sgy += gm * y;
+    }
+  }
+  // the four row groups of the wave hold the same columns: fold them
+#pragma unroll
+  for (int off = 16; off <= 32; off <<= 1) {
+    sg.x += __shfl_xor(sg.x, off, 64); sg.y += __shfl_xor(sg.y, off, 64);
+    sg.z += __shfl_xor(sg.z, off, 64); sg.w += __shfl_xor(sg.w, off, 64);
+    sgy.x += __shfl_xor(sgy.x, off, 64); sgy.y += __shfl_xor(sgy.y, off, 64);
+    sgy.z += __shfl_xor(sgy.z, off, 64); sgy.w += __shfl_xor(sgy.w, off, 64);
+  }
+  if (rs == 0 && c4 * 4 < width) {
+    float* dst = partial + (int64_t)wave * 2 * width;
+    const float a[4] = {sg.x, sg.y, sg.z, sg.w}, c[4] = {sgy.x, sgy.y, sgy.z, sgy.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (c4 * 4 + k < width) { dst[c4 * 4 + k] = a[k]; dst[width + c4 * 4 + k] = c[k]; }
+  }
+}
+
+bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// schedule shape shared by the support query and the launcher; returns 0 if unsupported
+int bwd_shape(const gnc_mlp_desc_t& d, int* nmm_out, int* nadd_out, int* T_out) {
+  const int L = d.num_linear;
+  if (L < 2 || L > GNC_MAX_LINEAR - 1 || d.activation != GNC_ACT_RELU || d.rows >= INT32_MAX || d.rows < 1) return 0;
+  const int H = d.out_dim[0], od = d.out_dim[L - 1];
+  if (H > KC || od > KC) return 0;
+  for (int l = 1; l < L; ++l)
+    if (d.in_dim[l] > KC || d.out_dim[l] > KC) return 0;
+  int nmm = 0, nadd = 0;
+  for (int s = 0; s < d.num_segments; ++s) {
+    const gnc_mlp_segment_t& g = d.seg[s];
+    if (g.width > KC || g.ld % 4 != 0 || !al16(g.ptr)) return 0;
+    if (g.mode == GNC_SEG_ADD) {
+      ++nadd;
+    } else {
+      if (nadd) return 0;
+      ++nmm;
+    }
+  }
+  if (nmm < 1 || nmm > 3 || (nadd != 0 && !(nadd == 2 && nmm == 1))) return 0;
+  const int T = tiles_for(H > od ? H : od);
+  if (T > 2) return 0;
+  *nmm_out = nmm;
+  *nadd_out = nadd;
+  *T_out = T;
+  return 1;
+}
+
+template <int HT, int NMM, int NADD>
+int launch_bwd(const gnc_mlp_desc_t& d, const BwdArgs& b, int total_chunks, size_t smem, int grid, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    int rc = gnc::check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_backward_data_kernel<HT, NMM, NADD>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                            "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    if (rc) return rc;
+    attr_set = true;
+  }
+  const int64_t num_wtiles = gnc::ceil_div(d.rows, RPW);
+  mlp_backward_data_kernel<HT, NMM, NADD>
+      <<<dim3((unsigned)grid), dim3(BNT), smem, stream>>>(d, b, (int)num_wtiles, total_chunks);
+  return gnc::check_launch("mlp_backward_data_kernel");
+}
+
+int bwd_grid(int64_t rows) {
+  int64_t grid = gnc::ceil_div(gnc::ceil_div(rows, RPW), BWAVES);
+  return (int)(grid > gnc::kNumCU ? gnc::kNumCU : grid);
+}
+
+}  // namespace
+
+extern "C" size_t gnc_sizeof_mlp_bwd_desc(void) { return sizeof(gnc_mlp_bwd_desc_t); }
+
+extern "C" int gnc_mlp_backward_supported(const gnc_mlp_desc_t* fwd) {
+  int rc = validate_desc(fwd, false);
+  if (rc) return rc;
+  int nmm, nadd, T;
+  if (!bwd_shape(*fwd, &nmm, &nadd, &T)) {
+    gnc::set_error("gnc_mlp_backward: shape outside the HIP backward kernel (needs ReLU, widths <= 64, aligned tables)");
+    return GNC_ERR_UNSUPPORTED;
+  }
+  return GNC_OK;
+}
+
+extern "C" int gnc_mlp_backward_f32(const gnc_mlp_bwd_desc_t* bd, void* stream_) {
+  if (!bd) { gnc::set_error("gnc_mlp_backward_f32: null descriptor"); return GNC_ERR_INVALID_ARGUMENT; }
+  const gnc_mlp_desc_t& d = bd->fwd;
+  int rc = validate_desc(&d, false);
+  if (rc) return rc;
+  int nmm, nadd, T;
+  if (!bwd_shape(d, &nmm, &nadd, &T)) {
+    gnc::set_error("gnc_mlp_backward_f32: shape outside the HIP backward kernel");
+    return GNC_ERR_UNSUPPORTED;
+  }
+  const int L = d.num_linear;
+  GNC_REQUIRE(bd->grad_out && bd->ld_grad_out % 4 == 0 && al16(bd->grad_out) && bd->ld_grad_out >= d.out_dim[L - 1],
+              "gnc_mlp_backward_f32: grad_out must be 16-B aligned with ld %% 4 == 0");
+  for (int l = 0; l < L; ++l) {
+    GNC_REQUIRE(bd->dz[l], "gnc_mlp_backward_f32: dz[%d] is null", l);
+    GNC_REQUIRE(l == L - 1 || bd->act[l], "gnc_mlp_backward_f32: act[%d] is null", l);
+  }
+  const int grid = bwd_grid(d.rows);
+  GNC_REQUIRE(!d.ln_gamma || bd->yhat, "gnc_mlp_backward_f32: yhat is required with LayerNorm");
+  GNC_REQUIRE(!bd->dx || bd->ld_dx >= d.in_dim[0], "gnc_mlp_backward_f32: ld_dx < in_dim[0]");
+
+  BwdArgs b = {};
+  b.grad_out = bd->grad_out;
+  b.ld_grad_out = bd->ld_grad_out;
+  for (int l = 0; l < L; ++l) { b.act[l] = bd->act[l]; b.dz[l] = bd->dz[l]; }
+  b.dx = bd->dx;
+  b.ld_dx = bd->ld_dx;
+  b.yhat = d.ln_gamma ? bd->yhat : nullptr;
+
+  const int total_chunks = nmm + (L - 1);
+  const size_t smem =
+      ((size_t)total_chunks * T * 32 * LDSW + (size_t)(L + 2) * T * 32 + (size_t)BWAVES * RPW * LDSW) * sizeof(float);
+  if (smem > 160 * 1024) { gnc::set_error("gnc_mlp_backward_f32: weights do not fit in LDS"); return GNC_ERR_UNSUPPORTED; }
+  hipStream_t stream = (hipStream_t)stream_;
+#define GNC_BWD(HT_, NMM_, NADD_) return launch_bwd<HT_, NMM_, NADD_>(d, b, total_chunks, smem, grid, stream)
+  if (T == 2) {
+    if (nadd == 2) GNC_BWD(2, 1, 2);
+    if (nmm == 1) GNC_BWD(2, 1, 0);
+    if (nmm == 2) GNC_BWD(2, 2, 0);
+    GNC_BWD(2, 3, 0);
+  }
+  if (nadd == 2) GNC_BWD(1, 1, 2);
+  if (nmm == 1) GNC_BWD(1, 1, 0);
+  if (nmm == 2) GNC_BWD(1, 2, 0);
+  GNC_BWD(1, 3, 0);
+#undef GNC_BWD
+}
+
+extern "C" int gnc_xty_partials(int64_t rows) {
+  int64_t tiles = gnc::ceil_div(rows > 0 ? rows : 1, RPW);
+  int64_t waves = tiles < 4 * gnc::kNumCU * 2 ? tiles : 4 * gnc::kNumCU * 2;  // <= 2 blocks of 4 waves per CU
+  waves = (waves + 3) / 4 * 4;
+  return (int)waves;
+}
+
+extern "C" int gnc_xty_f32(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t rows, int32_t M, int32_t K,
+                           float* partial, int32_t num_partials, void* stream_) {
+  GNC_REQUIRE(rows >= 1 && rows < INT32_MAX && M >= 1 && K >= 1 && M <= 64 && K <= 64, "gnc_xty_f32: need 1 <= M, K <= 64");
+  GNC_REQUIRE(A && B && partial && lda >= M && ldb >= K, "gnc_xty_f32: null pointer or leading dimension too small");
+  const int waves = gnc_xty_partials(rows);
+  GNC_REQUIRE(num_partials >= waves, "gnc_xty_f32: partial buffer smaller than gnc_xty_partials()");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int pstride = M * K + M;
+  dim3 grid((unsigned)(waves / 4)), block(256);
+  const int tm = M > 32 ? 2 : 1, tk = K > 32 ? 2 : 1;
+  if (tm == 2 && tk == 2) xty_kernel<2, 2><<<grid, block, 0, stream>>>(A, lda, B, ldb, (int)rows, M, K, partial, pstride);
+  else if (tm == 2) xty_kernel<2, 1><<<grid, block, 0, stream>>>(A, lda, B, ldb, (int)rows, M, K, partial, pstride);
+  else if (tk == 2) xty_kernel<1, 2><<<grid, block, 0, stream>>>(A, lda, B, ldb, (int)rows, M, K, partial, pstride);
+  else xty_kernel<1, 1><<<grid, block, 0, stream>>>(A, lda, B, ldb, (int)rows, M, K, partial, pstride);
+  return gnc::check_launch("xty_kernel");
+}
+
+extern "C" int gnc_colsum_pair_f32(const float* G, int64_t ldg, const float* Y, int64_t ldy, int64_t rows, int32_t width,
+                                   float* partial, int32_t num_partials, void* stream_) {
+  GNC_REQUIRE(rows >= 1 && rows < INT32_MAX && width >= 1 && width <= 64, "gnc_colsum_pair_f32: need width <= 64");
+  GNC_REQUIRE(G && Y && partial && ldg % 4 == 0 && ldy % 4 == 0 && al16(G) && al16(Y) && ldg >= width && ldy >= width,
+              "gnc_colsum_pair_f32: rows must be 16-B aligned with ld %% 4 == 0");
+  const int waves = gnc_xty_partials(rows);
+  GNC_REQUIRE(num_partials >= waves, "gnc_colsum_pair_f32: partial buffer smaller than gnc_xty_partials()");
+  colsum_pair_kernel<<<dim3((unsigned)(waves / 4)), dim3(256), 0, (hipStream_t)stream_>>>(G, ldg, Y, ldy, (int)rows, width,
+                                                                                          partial);
+  return gnc::check_launch("colsum_pair_kernel");
+}

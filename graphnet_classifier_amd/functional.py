@@ -14,7 +14,12 @@ from __future__ import annotations
 import torch
 import torch.nn.functional as F
 
+import os
+
 from . import native
+
+# GNC_TORCH_BACKWARD=1 keeps the PyTorch-ROCm recompute backward everywhere (A/B and parity checks)
+HIP_BACKWARD = os.environ.get("GNC_TORCH_BACKWARD") is None
 
 
 class _ScatterSumCSR(torch.autograd.Function):
@@ -92,6 +97,9 @@ class _FusedMLP(torch.autograd.Function):
         meta, args = ctx.meta, ctx.saved_tensors
         s, l = len(meta.indices), meta.num_linear
         need = ctx.needs_input_grad[1:]
+        hip = _fused_mlp_backward_hip(meta, args, need, grad_out) if HIP_BACKWARD else None
+        if hip is not None:
+            return (None,) + hip
         leaves = [a.detach().requires_grad_(bool(n)) for a, n in zip(args, need)]
         tables, weights, biases = leaves[:s], leaves[s:s + l], leaves[s + l:s + 2 * l]
         rest = leaves[s + 2 * l:]
@@ -109,6 +117,63 @@ class _FusedMLP(torch.autograd.Function):
             wanted = [x for x, n in zip(leaves, need) if n]
             grads = iter(torch.autograd.grad(h, wanted, grad_out.contiguous(), allow_unused=True))
         return (None,) + tuple(next(grads) if n else None for n in need)
+
+
+def _fused_mlp_backward_hip(meta: _MlpMeta, args, need, grad_out):
+    """Backward of one fused-MLP call on the HIP kernels (K8): data path + one skinny GEMM per Linear.
+    Returns the gradient tuple in argument order, or None when the shape is outside the kernels."""
+    s, l = len(meta.indices), meta.num_linear
+    tables, weights, biases = list(args[:s]), list(args[s:s + l]), list(args[s + l:s + 2 * l])
+    rest = list(args[s + 2 * l:])
+    ln = (rest[0], rest[1], meta.ln_eps) if meta.has_ln else None
+    residual = rest[-1] if meta.has_residual else None
+    segments = list(zip(tables, meta.indices))
+    if (meta.activation != "ReLU" or l < 2 or not grad_out.is_cuda
+            or not native.mlp_backward_supported(segments, weights, biases, ln, meta.activation, residual, meta.rows)):
+        return None
+    grad_out = grad_out.contiguous()
+    need_tables = any(need[:s])
+    r = native.mlp_backward(segments, weights, biases, ln, grad_out, rows=meta.rows, need_dx=need_tables)
+    grads = [None] * len(args)
+    # inputs: dx is in concat (= weight column) order
+    off = 0
+    layer0_inputs = []
+    for k, (t, idx) in enumerate(segments):
+        w = t.size(1)
+        rows_k = t if idx is None else native.gather_rows(t, idx)
+        layer0_inputs.append(rows_k)
+        if need[k]:
+            gk = r["dx"][:, off:off + w]
+            if idx is None:
+                grads[k] = gk
+            else:  # rows gathered by index: scatter the row gradients back (rare, operator-level API only)
+                grads[k] = torch.zeros_like(t).index_add_(0, idx.long(), gk)
+        off += w
+    # weights and biases: dW_l = dz_l^T (input of Linear l), db_l = column sums of dz_l
+    for k in range(l):
+        if not (need[s + k] or need[s + l + k]):
+            continue
+        dz = r["dz"][k]
+        if k == 0:
+            parts, db = [], None
+            for rows_k in layer0_inputs:
+                c, cs = native.xty(dz, rows_k)
+                parts.append(c)
+                db = cs if db is None else db
+            dw = torch.cat(parts, dim=1) if len(parts) > 1 else parts[0]
+        else:
+            dw, db = native.xty(dz, r["act"][k - 1])
+        grads[s + k] = dw if need[s + k] else None
+        grads[s + l + k] = db if need[s + l + k] else None
+    pos = s + 2 * l
+    if meta.has_ln:
+        dbeta, dgamma = native.colsum_pair(grad_out, r["yhat"])
+        grads[pos] = dgamma if need[pos] else None
+        grads[pos + 1] = dbeta if need[pos + 1] else None
+        pos += 2
+    if meta.has_residual and need[pos]:
+        grads[pos] = grad_out
+    return tuple(grads)
 
 
 def fused_mlp(segments, weights, biases, ln=None, activation: str = "ReLU", act_param: float = 0.0, residual=None,
@@ -135,7 +200,8 @@ class _EdgeProcessorWSplit(torch.autograd.Function):
     first two segments are gathered and ADDED.  args = x, e, weights[L], biases[L], gamma, beta."""
 
     @staticmethod
-    def forward(ctx, meta, x, e, *params):
+    def forward(ctx, meta, topo, x, e, *params):
+        ctx.topo = topo
         src, dst, num_linear, activation, act_param, ln_eps, has_ln = meta
         weights, biases = list(params[:num_linear]), list(params[num_linear:2 * num_linear])
         ln = (params[2 * num_linear], params[2 * num_linear + 1], ln_eps) if has_ln else None
@@ -153,7 +219,10 @@ class _EdgeProcessorWSplit(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         src, dst, num_linear, activation, act_param, ln_eps, has_ln = ctx.meta
-        need = ctx.needs_input_grad[1:]
+        need = ctx.needs_input_grad[2:]
+        hip = _edge_wsplit_backward_hip(ctx, grad_out) if HIP_BACKWARD else None
+        if hip is not None:
+            return (None, None) + hip
         leaves = [a.detach().requires_grad_(bool(n)) for a, n in zip(ctx.saved_tensors, need)]
         x, e, params = leaves[0], leaves[1], leaves[2:]
         act = _torch_activation(activation, act_param)
@@ -168,13 +237,69 @@ class _EdgeProcessorWSplit(torch.autograd.Function):
             h = h + e
             wanted = [t for t, n in zip(leaves, need) if n]
             grads = iter(torch.autograd.grad(h, wanted, grad_out.contiguous(), allow_unused=True))
-        return (None,) + tuple(next(grads) if n else None for n in need)
+        return (None, None) + tuple(next(grads) if n else None for n in need)
 
 
-def edge_processor_wsplit(x, e, src, dst, weights, biases, ln, activation="ReLU", act_param=0.0):
-    meta = (src, dst, len(weights), activation, float(act_param), float(ln[2]) if ln is not None else 0.0, ln is not None)
+def _edge_wsplit_backward_hip(ctx, grad_out):
+    """HIP backward of the W-split edge processor.  Per edge: the K8 data kernel (recompute + chain),
+    then dz0 is (i) the gradient of both gathered projections - summed per node through the two CSRs
+    (destination-sorted: the forward's; source-sorted: topo.csc) - and (ii) the left operand of dWe."""
+    src, dst, num_linear, activation, act_param, ln_eps, has_ln = ctx.meta
+    topo = ctx.topo
+    need = ctx.needs_input_grad[2:]
+    x, e = ctx.saved_tensors[0], ctx.saved_tensors[1]
+    params = list(ctx.saved_tensors[2:])
+    weights, biases = params[:num_linear], params[num_linear:2 * num_linear]
+    ln = (params[2 * num_linear], params[2 * num_linear + 1], ln_eps) if has_ln else None
+    if topo is None or activation != "ReLU" or not grad_out.is_cuda:
+        return None
+    dn = x.size(1)
+    w0 = weights[0]
+    h = w0.size(0)
+    ws_, wd_, we_ = w0[:, :dn], w0[:, dn:2 * dn], w0[:, 2 * dn:]
+    # the forward's projections are needed again as the gathered additive inputs
+    ps = native.mlp_forward([(x, None)], [ws_], [None])
+    pd = native.mlp_forward([(x, None)], [wd_], [None])
+    segments = [(ps, src), (pd, dst), (e, None)]
+    modes = [native.SEG_ADD, native.SEG_ADD, native.SEG_MATMUL]
+    wl = [we_] + weights[1:]
+    if not native.mlp_backward_supported(segments, wl, biases, ln, activation, e, e.size(0), modes):
+        return None
+    grad_out = grad_out.contiguous()
+    r = native.mlp_backward(segments, wl, biases, ln, grad_out, rows=e.size(0), modes=modes, need_dx=bool(need[1]))
+    dz0 = r["dz"][0]
+    grads = [None] * (2 + len(params))
+    if need[1]:
+        grads[1] = r["dx"] + grad_out  # through We, plus the residual path
+    # node side: d(ps)[v] = sum of dz0 over edges with src == v, d(pd)[v] = ... dst == v
+    csc_rowptr, csc_perm = topo.csc
+    dps = native.scatter_sum_csr(dz0, csc_rowptr, csc_perm, topo.num_nodes)
+    dpd = native.scatter_sum_csr(dz0, topo.rowptr, None, topo.num_nodes)
+    if need[0]:  # dx = dps Ws + dpd Wd: one projection launch over [dps | dpd] with the weight [Ws ; Wd]^T
+        wt = torch.cat([ws_, wd_], dim=0).t().contiguous()  # [dn, 2h]
+        grads[0] = native.mlp_forward([(dps, None), (dpd, None)], [wt], [None])
+    if need[2] or need[2 + num_linear]:
+        dws, _ = native.xty(dps, x)
+        dwd, _ = native.xty(dpd, x)
+        dwe, db0 = native.xty(dz0, e)
+        grads[2] = torch.cat([dws, dwd, dwe], dim=1)
+        grads[2 + num_linear] = db0
+    for k in range(1, num_linear):
+        dw, db = native.xty(r["dz"][k], r["act"][k - 1])
+        grads[2 + k] = dw
+        grads[2 + num_linear + k] = db
+    if has_ln:
+        dbeta, dgamma = native.colsum_pair(grad_out, r["yhat"])
+        grads[2 + 2 * num_linear] = dgamma
+        grads[2 + 2 * num_linear + 1] = dbeta
+    return tuple(g if n else None for g, n in zip(grads, need))
+
+
+def edge_processor_wsplit(x, e, topo, weights, biases, ln, activation="ReLU", act_param=0.0):
+    meta = (topo.src_sorted, topo.dst_sorted, len(weights), activation, float(act_param),
+            float(ln[2]) if ln is not None else 0.0, ln is not None)
     args = list(weights) + list(biases) + ([ln[0], ln[1]] if ln is not None else [])
-    return _EdgeProcessorWSplit.apply(meta, x, e, *args)
+    return _EdgeProcessorWSplit.apply(meta, topo, x, e, *args)
 
 
 def edge_features(pos: torch.Tensor, src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:

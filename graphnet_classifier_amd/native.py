@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 GNC_MAX_SEGMENTS = 4
 GNC_MAX_LINEAR = 8
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 ACTIVATIONS = {  # nn.<Name> accepted by the reference's MLP(activation=...) (models/MLP.py:21)
     "ReLU": 0, "Identity": 1, "Tanh": 2, "Sigmoid": 3, "SiLU": 4, "GELU": 5, "LeakyReLU": 6, "ELU": 7,
@@ -39,6 +39,12 @@ _SIGNATURES = {
     "gnc_sizeof_mlp_desc": (c_size_t, []),
     "gnc_mlp_supported": (c_int32, [c_void_p]),
     "gnc_mlp_forward_f32": (c_int32, [c_void_p, c_void_p]),
+    "gnc_sizeof_mlp_bwd_desc": (c_size_t, []),
+    "gnc_mlp_backward_supported": (c_int32, [c_void_p]),
+    "gnc_mlp_backward_f32": (c_int32, [c_void_p, c_void_p]),
+    "gnc_xty_partials": (c_int32, [c_int64]),
+    "gnc_xty_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, c_void_p, c_int32, c_void_p]),
+    "gnc_colsum_pair_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_int32, c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -62,6 +68,14 @@ class MlpDesc(Structure):
     ]
 
 
+class MlpBwdDesc(Structure):
+    _fields_ = [
+        ("fwd", MlpDesc), ("grad_out", c_void_p), ("ld_grad_out", c_int32),
+        ("act", c_void_p * GNC_MAX_LINEAR), ("dz", c_void_p * GNC_MAX_LINEAR),
+        ("dx", c_void_p), ("ld_dx", c_int32), ("yhat", c_void_p),
+    ]
+
+
 _lib = None
 
 
@@ -82,6 +96,9 @@ def load_library() -> ctypes.CDLL:
         fn.argtypes = args
     if lib.gnc_abi_version() != ABI_VERSION:
         raise RuntimeError(f"{LIB_NAME}: ABI version {lib.gnc_abi_version()} != expected {ABI_VERSION}")
+    if lib.gnc_sizeof_mlp_bwd_desc() != ctypes.sizeof(MlpBwdDesc):
+        raise RuntimeError(f"{LIB_NAME}: gnc_mlp_bwd_desc_t is {lib.gnc_sizeof_mlp_bwd_desc()} bytes in C but "
+                           f"{ctypes.sizeof(MlpBwdDesc)} in the ctypes binding")
     if lib.gnc_sizeof_mlp_desc() != ctypes.sizeof(MlpDesc):
         raise RuntimeError(f"{LIB_NAME}: gnc_mlp_desc_t is {lib.gnc_sizeof_mlp_desc()} bytes in C but "
                            f"{ctypes.sizeof(MlpDesc)} in the ctypes binding")
@@ -308,13 +325,8 @@ def _vector_rows(t: torch.Tensor, cache: bool = False) -> torch.Tensor:
 
 
 
-def mlp_forward(segments, weights, biases, ln=None, activation: str = "ReLU", act_param: float = 0.0,
-                residual: torch.Tensor | None = None, rows: int | None = None, modes=None) -> torch.Tensor:
-    """Fused MLP.  segments (in CONCAT order): list of (table [*, w] fp32, index int32 [rows] | None);
-    ``modes[s]`` is SEG_MATMUL (default) or SEG_ADD.  Weights may be column slices of a larger
-    matrix.  The segment that is also the residual is listed last for the kernel (its weight
-    columns are carried in ``wcol``), so the residual comes from the staged rows."""
-    lib = load_library()
+def _prepare_mlp(segments, weights, biases, residual, rows, modes):
+    """Shared argument preparation of the forward and backward launches (see mlp_forward)."""
     modes = list(modes) if modes is not None else [SEG_MATMUL] * len(segments)
     segs, wcol = [], 0
     for (table, index), mode in zip(segments, modes):
@@ -337,10 +349,21 @@ def mlp_forward(segments, weights, biases, ln=None, activation: str = "ReLU", ac
         rows = i0.numel() if i0 is not None else t0.size(0)
     weights = [_vector_rows(_rowmajor(w.detach()), cache=True) for w in weights]
     biases = [b.contiguous() if b is not None else None for b in biases]
-    dev = segs[0][0].device
-    out = torch.empty(rows, weights[-1].size(0), dtype=torch.float32, device=dev)
     if residual is not None:
         residual = _rowmajor(residual)
+    return segs, weights, biases, residual, rows, modes
+
+
+def mlp_forward(segments, weights, biases, ln=None, activation: str = "ReLU", act_param: float = 0.0,
+                residual: torch.Tensor | None = None, rows: int | None = None, modes=None) -> torch.Tensor:
+    """Fused MLP.  segments (in CONCAT order): list of (table [*, w] fp32, index int32 [rows] | None);
+    ``modes[s]`` is SEG_MATMUL (default) or SEG_ADD.  Weights may be column slices of a larger
+    matrix.  The segment that is also the residual is listed last for the kernel (its weight
+    columns are carried in ``wcol``), so the residual comes from the staged rows."""
+    lib = load_library()
+    segs, weights, biases, residual, rows, modes = _prepare_mlp(segments, weights, biases, residual, rows, modes)
+    dev = segs[0][0].device
+    out = torch.empty(rows, weights[-1].size(0), dtype=torch.float32, device=dev)
     desc = make_mlp_desc(segs, weights, biases, ln, activation, act_param, residual, out, rows)
     # executed FLOPs of this launch: 2 * rows * sum(in*out) over the Linear layers
     flops = 2.0 * rows * sum(w.size(0) * w.size(1) for w in weights)
@@ -351,3 +374,92 @@ def mlp_forward(segments, weights, biases, ln=None, activation: str = "ReLU", ac
                        lambda: lib.gnc_mlp_forward_f32(ctypes.byref(desc), _stream(out)), flops),
                "gnc_mlp_forward_f32")
     return out
+
+
+# --------------------------------------------------------------------------- K8 backward
+def mlp_backward_supported(segments, weights, biases, ln, activation, residual, rows, modes=None) -> bool:
+    """Shape query of the HIP backward kernel (ReLU, widths <= 64, 2..7 Linear layers ...)."""
+    lib = load_library()
+    if activation not in ACTIVATIONS or not (1 <= len(weights) <= GNC_MAX_LINEAR) or len(segments) > GNC_MAX_SEGMENTS:
+        return False
+    segs, w, b, res, rows, _ = _prepare_mlp(segments, weights, biases, residual, rows, modes)
+    dummy = torch.empty(1, w[-1].size(0), device=segs[0][0].device)
+    desc = make_mlp_desc(segs, w, b, ln, activation, 0.0, res, dummy, rows)
+    return lib.gnc_mlp_backward_supported(ctypes.byref(desc)) == 0
+
+
+def mlp_backward(segments, weights, biases, ln, grad_out: torch.Tensor, rows: int | None = None, modes=None,
+                 need_dx: bool = True):
+    """Data path of the MLP backward (see include/gnc_hip.h, K8).  Returns a dict with
+    ``act`` (inputs of Linear 1..L-1), ``dz`` (grads of every pre-activation, dz[-1] = pre-LayerNorm),
+    ``dx`` ([rows, in_dim0] in weight-column order, or None) and ``yhat`` (or None)."""
+    lib = load_library()
+    segs, w, b, _, rows, _ = _prepare_mlp(segments, weights, biases, None, rows, modes)
+    dev = segs[0][0].device
+    dummy = torch.empty(1, w[-1].size(0), device=dev)
+    bd = MlpBwdDesc()
+    bd.fwd = make_mlp_desc(segs, w, b, ln, "ReLU", 0.0, None, dummy, rows)
+    g = _vector_rows(_rowmajor(grad_out))
+    bd.grad_out, bd.ld_grad_out = g.data_ptr(), _ld(g)
+    n_lin = len(w)
+    act = [torch.empty(rows, w[l].size(0), dtype=torch.float32, device=dev) for l in range(n_lin - 1)]
+    dz = [torch.empty(rows, w[l].size(0), dtype=torch.float32, device=dev) for l in range(n_lin)]
+    for l in range(n_lin):
+        bd.dz[l] = dz[l].data_ptr()
+        if l < n_lin - 1:
+            bd.act[l] = act[l].data_ptr()
+    dx = torch.empty(rows, w[0].size(1), dtype=torch.float32, device=dev) if need_dx else None
+    if dx is not None:
+        bd.dx, bd.ld_dx = dx.data_ptr(), _ld(dx)
+    yhat = torch.empty(rows, w[-1].size(0), dtype=torch.float32, device=dev) if ln is not None else None
+    if yhat is not None:
+        bd.yhat = yhat.data_ptr()
+    flops = 2.0 * rows * (2 * sum(x.size(0) * x.size(1) for x in w))
+    with torch.cuda.device(dev):
+        _check(_launch(f"mlp_backward_in{w[0].size(1)}_h{w[0].size(0)}_out{w[-1].size(0)}_L{n_lin}", g,
+                       lambda: lib.gnc_mlp_backward_f32(ctypes.byref(bd), _stream(g)), flops), "gnc_mlp_backward_f32")
+    return {"act": act, "dz": dz, "dx": dx, "yhat": yhat, "_keep": (segs, w, b, g)}
+
+
+def xty(a: torch.Tensor, b: torch.Tensor):
+    """(A^T B [M, K], column sums of A [M]) over the rows; A [rows, M], B [rows, K] fp32.  Blocks of
+    64 x 64 per launch; per-wave partials are summed in a fixed order (bitwise reproducible)."""
+    lib = load_library()
+    _require_cuda(a, b)
+    a, b = _rowmajor(a), _rowmajor(b)
+    rows, m, k = a.size(0), a.size(1), b.size(1)
+    dev = a.device
+    c = torch.empty(m, k, dtype=torch.float32, device=dev)
+    colsum = torch.empty(m, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        p = lib.gnc_xty_partials(rows)
+        for m0 in range(0, m, 64):
+            mm = min(64, m - m0)
+            for k0 in range(0, k, 64):
+                kk = min(64, k - k0)
+                part = torch.empty(p, mm * kk + mm, dtype=torch.float32, device=dev)
+                av, bv = a[:, m0:m0 + mm], b[:, k0:k0 + kk]
+                _check(_launch("xty", av, lambda: lib.gnc_xty_f32(av.data_ptr(), _ld(av), bv.data_ptr(), _ld(bv), rows, mm,
+                                                                  kk, part.data_ptr(), p, _stream(av)),
+                               2.0 * rows * mm * kk), "gnc_xty_f32")
+                tot = part.sum(dim=0)
+                c[m0:m0 + mm, k0:k0 + kk] = tot[:mm * kk].view(mm, kk)
+                if k0 == 0:
+                    colsum[m0:m0 + mm] = tot[mm * kk:]
+    return c, colsum
+
+
+def colsum_pair(g: torch.Tensor, y: torch.Tensor):
+    """(column sums of G, column sums of G*Y): d beta and d gamma of a LayerNorm."""
+    lib = load_library()
+    g, y = _vector_rows(_rowmajor(g)), _vector_rows(_rowmajor(y))
+    rows, width = g.shape
+    if width > 64:
+        return g.sum(0), (g * y).sum(0)  # wide LayerNorm: PyTorch-ROCm reduction
+    with torch.cuda.device(g.device):
+        p = lib.gnc_xty_partials(rows)
+        part = torch.empty(p, 2 * width, dtype=torch.float32, device=g.device)
+        _check(lib.gnc_colsum_pair_f32(g.data_ptr(), _ld(g), y.data_ptr(), _ld(y), rows, width, part.data_ptr(), p,
+                                       _stream(g)), "gnc_colsum_pair_f32")
+    tot = part.sum(dim=0)
+    return tot[:width], tot[width:]

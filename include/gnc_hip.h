@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GNC_ABI_VERSION 4
+#define GNC_ABI_VERSION 5
 
 enum {
   GNC_OK = 0,
@@ -168,6 +168,48 @@ typedef struct gnc_mlp_desc {
 size_t gnc_sizeof_mlp_desc(void);
 int gnc_mlp_supported(const gnc_mlp_desc_t* desc /* host */);
 int gnc_mlp_forward_f32(const gnc_mlp_desc_t* desc /* host */, void* stream);
+
+/* ---- K8: backward of the fused MLP ---------------------------------------------------------
+ * Replaces what PyTorch's autograd does for `loss.backward()` (utils/train_model.py:41) through
+ * models/MLP.py:45-47 and the concat/residual around it.  Two kernels:
+ *
+ * gnc_mlp_backward_f32: given the forward description `fwd` (its `out` field is ignored) and
+ *   grad_out = dL/d(out) [rows, out_dim], recomputes the forward per 32-row tile and writes
+ *     act[l]  [rows, out_dim[l]]  post-activation output of Linear l, l < num_linear-1 (input of Linear l+1)
+ *     dz[l]   [rows, out_dim[l]]  dL/d(pre-activation of Linear l); dz[num_linear-1] is dL/d(pre-LayerNorm y)
+ *     dx      [rows, in_dim[0]]   dL/d(MATMUL part of the input concat), column order = wcol; NULL to skip
+ *     yhat    [rows, out_dim]     normalised pre-affine output of the LayerNorm (required with LayerNorm):
+ *                                 d beta = colsum(grad_out), d gamma = colsum(grad_out * yhat) -> gnc_colsum_pair_f32
+ *   The gradient of an ADD segment's table rows is dz[0] itself (scatter it by the segment's index);
+ *   the gradient of the residual is grad_out.  Weight gradients: dW_l = dz[l]^T (input of Linear l),
+ *   db_l = column sums of dz[l] -> gnc_xty_f32.
+ *   Supported: ReLU, 2 <= num_linear <= 7, every width and every segment <= 64 columns, tables 16-B
+ *   aligned with ld % 4 == 0, MATMUL segments listed before ADD segments (0 or 2 of them);
+ *   gnc_mlp_backward_supported() answers from the shape fields alone.
+ *
+ * gnc_xty_f32: partial[w] = [ A^T B (M x K, row-major) | column sums of A (M) ] over the rows wave w
+ *   streamed; sum the num_partials = gnc_xty_partials(rows) rows (fixed order => reproducible).  M, K <= 64.
+ * gnc_colsum_pair_f32: partial[w] = [ colsum(G) (width) | colsum(G * Y) (width) ], same partial count.
+ */
+typedef struct gnc_mlp_bwd_desc {
+  gnc_mlp_desc_t fwd;
+  const float* grad_out;
+  int32_t ld_grad_out;
+  float* act[GNC_MAX_LINEAR];
+  float* dz[GNC_MAX_LINEAR];
+  float* dx;
+  int32_t ld_dx;
+  float* yhat;
+} gnc_mlp_bwd_desc_t;
+
+size_t gnc_sizeof_mlp_bwd_desc(void);
+int gnc_mlp_backward_supported(const gnc_mlp_desc_t* fwd /* host */);
+int gnc_mlp_backward_f32(const gnc_mlp_bwd_desc_t* desc /* host */, void* stream);
+int gnc_xty_partials(int64_t rows);
+int gnc_xty_f32(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t rows, int32_t M, int32_t K,
+                float* partial, int32_t num_partials, void* stream);
+int gnc_colsum_pair_f32(const float* G, int64_t ldg, const float* Y, int64_t ldy, int64_t rows, int32_t width,
+                        float* partial, int32_t num_partials, void* stream);
 
 #ifdef __cplusplus
 }

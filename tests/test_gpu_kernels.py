@@ -274,3 +274,91 @@ def test_mlp_rejects_unsupported(native):
         native.mlp_forward([(x, None)], w, b)
     with pytest.raises(NotImplementedError):
         native.mlp_forward([(x, None)], [w[0][:8], w[1][:, :8]], [b[0][:8], b[1]], activation="Softplus")
+
+
+# ------------------------------------------------------------------ K8 backward kernels
+@pytest.mark.parametrize("m,k", [(64, 64), (64, 3), (16, 40), (128, 64), (64, 192)])
+def test_xty_matches_matmul(native, m, k):
+    rng = np.random.default_rng(m * 7 + k)
+    rows = 4099
+    a = torch.from_numpy(rng.standard_normal((rows, m)).astype(np.float32))
+    b = torch.from_numpy(rng.standard_normal((rows, k)).astype(np.float32))
+    c, cs = native.xty(a.to(DEV), b.to(DEV))
+    ref = a.double().t() @ b.double()
+    assert max_abs(c.cpu(), ref.float()) < 2e-3  # sums of ~4k products of O(1) values in fp32
+    assert float((c.cpu().double() - ref).abs().max() / ref.abs().max()) < 2e-5
+    assert max_abs(cs.cpu(), a.double().sum(0).float()) < 1e-3
+    c2, _ = native.xty(a.to(DEV), b.to(DEV))
+    assert torch.equal(c, c2)  # fixed summation order
+
+
+def test_colsum_pair(native):
+    rng = np.random.default_rng(9)
+    g = torch.from_numpy(rng.standard_normal((5003, 64)).astype(np.float32))
+    y = torch.from_numpy(rng.standard_normal((5003, 64)).astype(np.float32))
+    sg, sgy = native.colsum_pair(g.to(DEV), y.to(DEV))
+    assert max_abs(sg.cpu(), g.double().sum(0).float()) < 1e-3
+    assert max_abs(sgy.cpu(), (g.double() * y.double()).sum(0).float()) < 1e-3
+
+
+def _torch_mlp(sd, x_cat, residual=None):
+    h = x_cat
+    keys = sorted({int(k.split(".")[2]) for k in sd})
+    lin = [i for i in keys if sd[f"m.model.{i}.weight"].ndim == 2]
+    for n, i in enumerate(lin):
+        h = torch.nn.functional.linear(h, sd[f"m.model.{i}.weight"], sd[f"m.model.{i}.bias"])
+        if n + 1 < len(lin):
+            h = torch.relu(h)
+    norm = [i for i in keys if sd[f"m.model.{i}.weight"].ndim == 1]
+    for i in norm:
+        h = torch.nn.functional.layer_norm(h, (h.size(-1),), sd[f"m.model.{i}.weight"], sd[f"m.model.{i}.bias"], 1e-5)
+    return h + residual if residual is not None else h
+
+
+@pytest.mark.parametrize("in_dims,hidden,out_dim,hl,ln,res", [
+    ((64,), 64, 64, 2, True, False),
+    ((64, 64), 64, 64, 2, True, True),     # node processor: [x | agg], residual x
+    ((64, 64, 64), 64, 64, 2, True, True),  # edge processor, concat form
+    ((4,), 64, 64, 2, True, False),        # encoder
+    ((64,), 64, 1, 2, False, False),       # decoder
+    ((16, 16), 16, 16, 1, True, True),
+    ((20,), 32, 8, 3, True, False),
+])
+def test_mlp_backward_kernel_matches_autograd(native, in_dims, hidden, out_dim, hl, ln, res):
+    """dz / act / dx / yhat of the K8 data kernel and the xty weight gradients against torch.autograd
+    of the same MLP in float64."""
+    rng = np.random.default_rng(sum(in_dims) + hidden + out_dim)
+    rows = 1000
+    in_dim = sum(in_dims)
+    sd = _mlp_sd(rng, in_dim, hidden, out_dim, hl, ln)
+    tabs = [torch.from_numpy(rng.standard_normal((rows, w)).astype(np.float32)) for w in in_dims]
+    residual = tabs[0] if res else None
+    gout = torch.from_numpy(rng.standard_normal((rows, out_dim)).astype(np.float32))
+    # float64 reference
+    sd64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    t64 = [t.double().requires_grad_(True) for t in tabs]
+    y = _torch_mlp(sd64, torch.cat(t64, -1), t64[0] if res else None)
+    y.backward(gout.double())
+    # HIP
+    ws = [sd[k].to(DEV) for k in sorted((k for k in sd if sd[k].ndim == 2), key=lambda k: int(k.split(".")[2]))]
+    bs = [sd[k.replace("weight", "bias")].to(DEV) for k in sorted((k for k in sd if sd[k].ndim == 2), key=lambda k: int(k.split(".")[2]))]
+    lnk = [k for k in sd if k.endswith("weight") and sd[k].ndim == 1]
+    lnp = (sd[lnk[0]].to(DEV), sd[lnk[0].replace("weight", "bias")].to(DEV), 1e-5) if lnk else None
+    segs = [(t.to(DEV), None) for t in tabs]
+    assert native.mlp_backward_supported(segs, ws, bs, lnp, "ReLU", residual.to(DEV) if res else None, rows)
+    r = native.mlp_backward(segs, ws, bs, lnp, gout.to(DEV), rows=rows, need_dx=True)
+    dx_ref = torch.cat([t.grad for t in t64], -1)
+    if res:
+        dx_ref[:, :in_dims[0]] -= gout.double()  # the kernel's dx excludes the residual path
+    assert max_abs(r["dx"].cpu(), dx_ref.float()) < 2e-5
+    lin_keys = sorted((k for k in sd if sd[k].ndim == 2), key=lambda k: int(k.split(".")[2]))
+    for li, k in enumerate(lin_keys):
+        inp = torch.cat(tabs, -1).to(DEV) if li == 0 else r["act"][li - 1]
+        dw, db = native.xty(r["dz"][li], inp)
+        gw, gb = sd64[k].grad, sd64[k.replace("weight", "bias")].grad
+        assert float((dw.cpu().double() - gw).abs().max()) < 1e-4 * max(1.0, float(gw.abs().max())), k
+        assert float((db.cpu().double() - gb).abs().max()) < 1e-4 * max(1.0, float(gb.abs().max())), k
+    if lnk:
+        dbeta, dgamma = native.colsum_pair(gout.to(DEV), r["yhat"])
+        assert float((dgamma.cpu().double() - sd64[lnk[0]].grad).abs().max()) < 1e-3
+        assert float((dbeta.cpu().double() - sd64[lnk[0].replace("weight", "bias")].grad).abs().max()) < 1e-3
