@@ -102,6 +102,9 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(synthetic.WORKLOADS))
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="forward", choices=["forward", "train"],
+                    help="train: forward + cross-entropy + backward (HIP K8 kernels) + one flat gradient all-reduce "
+                         "(RCCL, world > 1) + Adam, graphs batched block-diagonally (c3/c5 only: equal-size graphs)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -133,10 +136,34 @@ def main():
     model.eval()
     x, pos, ei = batch.x.to(dev), batch.pos.to(dev), batch.edge_index.to(dev)
 
-    def step():
-        clear_topology_cache()  # the CSR build belongs to the step
-        with torch.no_grad():
-            return model(x, pos, ei)
+    if a.mode == "train":
+        from graphnet_classifier_amd.GNN import CombinedModel
+        from graphnet_classifier_amd.sharding import FlatGradAllReduce
+        nodes_per_graph = batch.num_nodes // batch.num_graphs
+        if nodes_per_graph * batch.num_graphs != batch.num_nodes or a.workload == "c2":
+            sys.exit("--mode train needs equal-size graphs (workloads c3, c5)")
+        torch.manual_seed(0)
+        cmodel = CombinedModel(GraphNet(**kw), num_nodes=nodes_per_graph, classes=2).to(dev)
+        cmodel.train()
+        labels = torch.randint(0, 2, (batch.num_graphs,), generator=torch.Generator().manual_seed(rank)).to(dev)
+        opt = torch.optim.Adam(cmodel.parameters(), lr=1e-3)   # utils/train_model.py:9
+        crit = torch.nn.CrossEntropyLoss()                     # utils/train_model.py:10
+        reducer = FlatGradAllReduce(cmodel.parameters())
+
+        def step():
+            clear_topology_cache()
+            logits = cmodel.forward_batched(x, pos, ei, batch.num_graphs)
+            loss = crit(logits, labels)
+            opt.zero_grad()
+            loss.backward()
+            reducer()  # ONE all-reduce of the flat gradient buffer (no-op at world size 1)
+            opt.step()
+            return logits
+    else:
+        def step():
+            clear_topology_cache()  # the CSR build belongs to the step
+            with torch.no_grad():
+                return model(x, pos, ei)
 
     def fence():
         torch.cuda.synchronize()
@@ -178,13 +205,16 @@ def main():
         mlp = ksum[mlp_name]
         mlp_tflops = mlp["avg_work"] / (mlp["avg_ms"] * 1e-3) / 1e12
         result = {
-            "metric": "edges aggregated/sec (GraphNet forward)", "value": tot_edges * n_blocks * a.steps / elapsed,
+            "metric": "edges aggregated/sec (GraphNet forward)" if a.mode == "forward" else
+                      "edges aggregated/sec (GraphNet+classifier training step: fwd+bwd+allreduce+Adam)",
+            "value": tot_edges * n_blocks * a.steps / elapsed,
             "unit": "edges/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": a.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{a.workload}: {w['desc']}", "graphs": int(tot_graphs), "nodes": int(tot_nodes),
                        "edges": int(tot_edges), "n_blocks": n_blocks, "width": w["width"],
-                       "step": "CSR build + GraphNet.forward, inputs resident in HBM"},
+                       "step": "CSR build + GraphNet.forward, inputs resident in HBM" if a.mode == "forward" else
+                               "CSR build + forward + CE loss + backward + flat grad all-reduce + Adam, inputs resident in HBM"},
             "graphs_per_sec": tot_graphs * a.steps / elapsed,
             "roofline": {"kernel": "scatter_sum_csr_vec4 (K1 scatter-sum aggregation, CSR-ordered messages)",
                          "bound": "hbm", "achieved": k1_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -197,7 +227,7 @@ def main():
                              "launches": mlp["launches"], "executed_flops_per_launch": mlp["avg_work"]},
             "kernel_ms_per_step": {k: v["avg_ms"] * v["launches"] / a.steps for k, v in ksum.items()},
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.mode == "forward":
             base, (s, yref) = cpu_baseline(batch, kw, n_blocks)
             result["cpu_baseline"] = base
             result["parity_max_abs_vs_oracle"] = float((y[: s.num_nodes].cpu() - yref).abs().max())

@@ -333,12 +333,21 @@ template <int TM, int TK>
 __global__ __launch_bounds__(256) void xty_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
                                                   int64_t ldb, int rows, int M, int K, float* __restrict__ partial,
                                                   int pstride) {
+  // Rows arrive as whole 16-B pieces (coalesced), are parked in a wave-private LDS tile and are read back
+  // down the columns (ds_read_b32) as MFMA operands: lane (i, h) of step s needs row 2s+h, column 32t+i.
+  __shared__ __attribute__((aligned(16))) float tiles[4][2][RPW * LDSW];
   const int lane = threadIdx.x & 63;
   const int i = lane & 31;
   const int h = lane >> 5;
+  const int c4 = lane & 15, rs = lane >> 4;
+  const int wib = threadIdx.x >> 6;
   const int wave = ((int)blockIdx.x * (int)blockDim.x + (int)threadIdx.x) >> 6;
   const int total_waves = ((int)gridDim.x * (int)blockDim.x) >> 6;
   const int num_tiles = (rows + RPW - 1) / RPW;
+  float* ta = tiles[wib][0];
+  float* tb = tiles[wib][1];
+  const bool avec = (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15u) == 0);
+  const bool bvec = (ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(B) & 15u) == 0);
   f32x16 acc[TM][TK];
 #pragma unroll
   for (int a = 0; a < TM; ++a)
@@ -349,29 +358,56 @@ __global__ __launch_bounds__(256) void xty_kernel(const float* __restrict__ A, i
   float csum[TM];
 #pragma unroll
   for (int a = 0; a < TM; ++a) csum[a] = 0.f;
-  const int ia[2] = {i < M ? i : 0, 32 + i < M ? 32 + i : 0};
-  const int ib[2] = {i < K ? i : 0, 32 + i < K ? 32 + i : 0};
-  const bool oka[2] = {i < M, 32 + i < M};
-  const bool okb[2] = {i < K, 32 + i < K};
 
-  for (int tile = wave; tile < num_tiles; tile += total_waves) {
-    const int row0 = tile * RPW;
+  auto load_tile = [&](f32x4 (&pre)[NP], const float* base, int64_t ld, int width, bool vec, int tile) {
+    const int col = c4 * 4;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int r = tile * RPW + p * 4 + rs;
+      const int rc = r < rows ? r : rows - 1;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (vec) {
+        const int cc = col < width ? col : 0;
+        v = *reinterpret_cast<const f32x4*>(base + (int64_t)rc * ld + cc);
+      } else {  // narrow / unaligned operand (e.g. the 3-column inputs): scalar, still unconditional
+        const float* q = base + (int64_t)rc * ld;
+        v.x = q[col + 0 < width ? col + 0 : 0]; v.y = q[col + 1 < width ? col + 1 : 0];
+        v.z = q[col + 2 < width ? col + 2 : 0]; v.w = q[col + 3 < width ? col + 3 : 0];
+      }
+      const bool rok = r < rows;
+      v.x = (rok && col + 0 < width) ? v.x : 0.f; v.y = (rok && col + 1 < width) ? v.y : 0.f;
+      v.z = (rok && col + 2 < width) ? v.z : 0.f; v.w = (rok && col + 3 < width) ? v.w : 0.f;
+      pre[p] = v;
+    }
+  };
+
+  int tile = wave;
+  f32x4 pa[NP], pb[NP];
+  if (tile < num_tiles) {
+    load_tile(pa, A, lda, M, avec, tile);
+    load_tile(pb, B, ldb, K, bvec, tile);
+  }
+  for (; tile < num_tiles; tile += total_waves) {
+    compiler_lds_barrier();
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      *reinterpret_cast<f32x4*>(ta + (p * 4 + rs) * LDSW + c4 * 4) = pa[p];
+      *reinterpret_cast<f32x4*>(tb + (p * 4 + rs) * LDSW + c4 * 4) = pb[p];
+    }
+    compiler_lds_barrier();
+    const int nt = tile + total_waves;  // next tile's rows fly while this one is multiplied (clamped: always legal)
+    load_tile(pa, A, lda, M, avec, nt < num_tiles ? nt : num_tiles - 1);
+    load_tile(pb, B, ldb, K, bvec, nt < num_tiles ? nt : num_tiles - 1);
 #pragma unroll 4
     for (int s = 0; s < RPW / 2; ++s) {
-      const int r = row0 + 2 * s + h;
-      const int rc = r < rows ? r : rows - 1;
       float av[TM], bv[TK];
 #pragma unroll
       for (int a = 0; a < TM; ++a) {
-        const float v = A[(int64_t)rc * lda + ia[a]];
-        av[a] = (r < rows && oka[a]) ? v : 0.f;
+        av[a] = ta[(2 * s + h) * LDSW + 32 * a + i];
         csum[a] += av[a];
       }
 #pragma unroll
-      for (int c = 0; c < TK; ++c) {
-        const float v = B[(int64_t)rc * ldb + ib[c]];
-        bv[c] = (r < rows && okb[c]) ? v : 0.f;
-      }
+      for (int c = 0; c < TK; ++c) bv[c] = tb[(2 * s + h) * LDSW + 32 * c + i];
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll
