@@ -1,0 +1,297 @@
+// Device-side graph construction for the inputs of the hot path.
+//
+// Replaces, for an image that is already a resized uint8 RGB array,
+//   utils/image_to_graph/image_to_graph_optimized.py:7-39, :69-79   (grid edges, pixel nodes)
+//   utils/image_to_graph/image_to_graph_patch.py:30-52               (patch nodes)
+//   utils/image_to_graph/image_to_graph_superpixel.py:36-71          (everything after the SLIC call:
+//       per-segment mean colour and centroid, region adjacency)
+// and emits the tensors utils/dataloader.py:49-51 would build (x, pos float32; edge_index int64) directly
+// in HBM, in the reference's node and edge ORDER.  The reference's region adjacency is an O(S^2 * H*W)
+// loop of binary dilations (1.4 - 2.6 s per image); here every pixel compares its
+// label with its right and lower neighbour, the (lo, hi) pairs are radix-sorted and made unique
+// (rocPRIM), and each surviving pair is written as [i,j],[j,i] - the same list, in the same
+// lexicographic order.  All sums are integer (exact) and only integer atomics are used, so the result
+// is deterministic.
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_select.hpp>
+
+#include "gnc_common.h"
+
+namespace {
+
+constexpr size_t kAlign = 256;
+inline size_t align_up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
+
+int grid_for(int64_t n) {
+  int64_t g = gnc::ceil_div(n > 0 ? n : 1, gnc::kBlock);
+  const int64_t cap = gnc::kNumCU * 8;
+  return (int)(g < cap ? g : cap);
+}
+
+__global__ void grid_edges_kernel(int H, int W, int diagonals, int64_t E, int64_t* __restrict__ ei) {
+  const int64_t eh = (int64_t)H * (W - 1), ev = (int64_t)(H - 1) * W, ed = (int64_t)(H - 1) * (W - 1);
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; e < E; e += stride) {
+    int64_t src, dst;
+    if (e < eh) {  // left -> right, row-major over (r, c < W-1)
+      const int64_t r = e / (W - 1), c = e % (W - 1);
+      src = r * W + c; dst = src + 1;
+    } else if (e < eh + ev) {  // top -> bottom
+      src = e - eh; dst = src + W;
+    } else if (e < eh + ev + ed) {  // top-left -> bottom-right
+      const int64_t k = e - eh - ev, r = k / (W - 1), c = k % (W - 1);
+      src = r * W + c; dst = (r + 1) * W + c + 1;
+    } else {  // top-right -> bottom-left
+      const int64_t k = e - eh - ev - ed, r = k / (W - 1), c = k % (W - 1);
+      src = r * W + c + 1; dst = (r + 1) * W + c;
+    }
+    (void)diagonals;
+    ei[e] = src;
+    ei[E + e] = dst;
+  }
+}
+
+__global__ void pixel_nodes_kernel(const uint8_t* __restrict__ img, int H, int W, int C, float* __restrict__ x,
+                                   float* __restrict__ pos) {
+  const int64_t n = (int64_t)H * W;
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; p < n; p += stride) {
+    for (int c = 0; c < C; ++c) x[p * C + c] = (float)img[p * C + c];  // raw 0..255, not normalised (optimized.py:73)
+    pos[2 * p] = (float)(p / W);
+    pos[2 * p + 1] = (float)(p % W);
+  }
+}
+
+__global__ void patch_nodes_kernel(const uint8_t* __restrict__ img, int H, int W, int C, int ps, float* __restrict__ x,
+                                   float* __restrict__ pos) {
+  const int nh = H / ps, nw = W / ps;
+  const int64_t total = (int64_t)nh * nw * C;
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; t < total; t += stride) {
+    const int c = (int)(t % C);
+    const int64_t pidx = t / C;
+    const int pi = (int)(pidx / nw), pj = (int)(pidx % nw);
+    unsigned sum = 0;  // uint8 sums are exact
+    for (int a = 0; a < ps; ++a)
+      for (int b = 0; b < ps; ++b) sum += img[((int64_t)(pi * ps + a) * W + (pj * ps + b)) * C + c];
+    x[pidx * C + c] = (float)((double)sum / (double)(ps * ps));  // np.mean(uint8) in float64, then float32
+    if (c == 0) {
+      pos[2 * pidx] = (float)(pi * ps + ps / 2);
+      pos[2 * pidx + 1] = (float)(pj * ps + ps / 2);
+    }
+  }
+}
+
+// ---- region adjacency graph -------------------------------------------------------------------------
+struct RagWs {
+  int32_t* present;   // [HW + 1] label l occurs
+  int32_t* rank;      // [HW + 1] exclusive scan: dense index of label l; rank[HW] = S
+  uint32_t* cnt;      // [HW]   pixels per segment
+  uint32_t* sum_rgb;  // [HW*3]
+  unsigned long long* sum_yx;  // [HW*2]
+  uint64_t* keys;     // [2*HW] candidate (lo << 32 | hi) pairs, sentinel for "no boundary"
+  uint64_t* sorted;   // [2*HW]
+  uint64_t* uniq;     // [2*HW]
+  int32_t* nuniq;     // [1]
+  void* prim_tmp;
+  size_t prim_bytes;
+};
+
+constexpr uint64_t kNoPair = ~0ull;
+
+__global__ void rag_mark(const int32_t* __restrict__ labels, int64_t n, int32_t* __restrict__ present,
+                         int32_t* __restrict__ status) {
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; p < n; p += stride) {
+    const int32_t l = labels[p];
+    if (l < 0 || l >= n) { *status = 1; continue; }
+    present[l] = 1;
+  }
+}
+
+__global__ void rag_accumulate(const int32_t* __restrict__ labels, const uint8_t* __restrict__ img, int H, int W,
+                               const int32_t* __restrict__ rank, uint32_t* __restrict__ cnt,
+                               uint32_t* __restrict__ sum_rgb, unsigned long long* __restrict__ sum_yx,
+                               uint64_t* __restrict__ keys) {
+  const int64_t n = (int64_t)H * W;
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; p < n; p += stride) {
+    const int32_t l = labels[p];
+    uint64_t kr = kNoPair, kd = kNoPair;
+    if (l >= 0 && l < n) {
+      const int r = (int)(p / W), c = (int)(p % W);
+      const int32_t s = rank[l];
+      atomicAdd(&cnt[s], 1u);
+      atomicAdd(&sum_rgb[3 * s + 0], (unsigned)img[3 * p + 0]);
+      atomicAdd(&sum_rgb[3 * s + 1], (unsigned)img[3 * p + 1]);
+      atomicAdd(&sum_rgb[3 * s + 2], (unsigned)img[3 * p + 2]);
+      atomicAdd(&sum_yx[2 * s + 0], (unsigned long long)r);
+      atomicAdd(&sum_yx[2 * s + 1], (unsigned long long)c);
+      if (c + 1 < W) {
+        const int32_t l2 = labels[p + 1];
+        if (l2 != l && l2 >= 0 && l2 < n) {
+          const uint32_t a = (uint32_t)s, b = (uint32_t)rank[l2];
+          kr = a < b ? ((uint64_t)a << 32) | b : ((uint64_t)b << 32) | a;
+        }
+      }
+      if (r + 1 < H) {
+        const int32_t l2 = labels[p + W];
+        if (l2 != l && l2 >= 0 && l2 < n) {
+          const uint32_t a = (uint32_t)s, b = (uint32_t)rank[l2];
+          kd = a < b ? ((uint64_t)a << 32) | b : ((uint64_t)b << 32) | a;
+        }
+      }
+    }
+    keys[2 * p] = kr;
+    keys[2 * p + 1] = kd;
+  }
+}
+
+__global__ void rag_nodes(const int32_t* __restrict__ rank, int64_t n, const uint32_t* __restrict__ cnt,
+                          const uint32_t* __restrict__ sum_rgb, const unsigned long long* __restrict__ sum_yx,
+                          float* __restrict__ x, float* __restrict__ pos) {
+  const int32_t S = rank[n];
+  int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; s < S; s += stride) {
+    const double c = (double)cnt[s];
+    for (int k = 0; k < 3; ++k) x[3 * s + k] = (float)(((double)sum_rgb[3 * s + k] / 255.0) / c);  // img_as_float mean
+    pos[2 * s] = (float)((double)sum_yx[2 * s] / c);      // centroid y (superpixel.py:47-49)
+    pos[2 * s + 1] = (float)((double)sum_yx[2 * s + 1] / c);
+  }
+}
+
+__global__ void rag_edges(const uint64_t* __restrict__ uniq, const int32_t* __restrict__ nuniq,
+                          const int32_t* __restrict__ rank, int64_t n, int64_t* __restrict__ ei, int64_t ld,
+                          int32_t* __restrict__ counts) {
+  const int32_t nu = *nuniq;
+  const int32_t valid = (nu > 0 && uniq[nu - 1] == kNoPair) ? nu - 1 : nu;  // the sentinel sorts last
+  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  if (k == 0) { counts[0] = rank[n]; counts[1] = 2 * valid; }
+  for (; k < valid; k += stride) {
+    const int64_t lo = (int64_t)(uniq[k] >> 32), hi = (int64_t)(uniq[k] & 0xffffffffu);
+    ei[2 * k] = lo;          ei[ld + 2 * k] = hi;       // [i, j]
+    ei[2 * k + 1] = hi;      ei[ld + 2 * k + 1] = lo;   // [j, i]   (superpixel.py:65-66)
+  }
+}
+
+size_t rag_prim_bytes(int64_t n) {
+  size_t a = 0, b = 0, c = 0;  // size queries: the status is irrelevant (a failing query leaves 0 and the build fails later)
+  (void)rocprim::exclusive_scan(nullptr, a, (const int32_t*)nullptr, (int32_t*)nullptr, 0, (size_t)(n + 1), rocprim::plus<int32_t>());
+  (void)rocprim::radix_sort_keys(nullptr, b, (const uint64_t*)nullptr, (uint64_t*)nullptr, (size_t)(2 * n));
+  (void)rocprim::unique(nullptr, c, (const uint64_t*)nullptr, (uint64_t*)nullptr, (int32_t*)nullptr, (size_t)(2 * n));
+  size_t m = a > b ? a : b;
+  return m > c ? m : c;
+}
+
+bool carve(void* ws, size_t bytes, int64_t n, RagWs* w) {
+  uintptr_t p = (reinterpret_cast<uintptr_t>(ws) + kAlign - 1) / kAlign * kAlign;
+  const uintptr_t end = reinterpret_cast<uintptr_t>(ws) + bytes;
+  auto take = [&](size_t b) { uintptr_t r = p; p += align_up(b); return r; };
+  w->present = reinterpret_cast<int32_t*>(take((size_t)(n + 1) * 4));
+  w->rank = reinterpret_cast<int32_t*>(take((size_t)(n + 1) * 4));
+  w->cnt = reinterpret_cast<uint32_t*>(take((size_t)n * 4));
+  w->sum_rgb = reinterpret_cast<uint32_t*>(take((size_t)n * 12));
+  w->sum_yx = reinterpret_cast<unsigned long long*>(take((size_t)n * 16));
+  w->keys = reinterpret_cast<uint64_t*>(take((size_t)n * 16));
+  w->sorted = reinterpret_cast<uint64_t*>(take((size_t)n * 16));
+  w->uniq = reinterpret_cast<uint64_t*>(take((size_t)n * 16));
+  w->nuniq = reinterpret_cast<int32_t*>(take(4));
+  w->prim_bytes = rag_prim_bytes(n);
+  w->prim_tmp = reinterpret_cast<void*>(take(w->prim_bytes));
+  return p <= end;
+}
+
+}  // namespace
+
+extern "C" int64_t gnc_grid_num_edges(int32_t H, int32_t W, int32_t diagonals) {
+  if (H < 1 || W < 1) return 0;
+  int64_t e = (int64_t)H * (W - 1) + (int64_t)(H - 1) * W;
+  if (diagonals) e += 2 * (int64_t)(H - 1) * (W - 1);
+  return e;
+}
+
+extern "C" int gnc_grid_edges_i64(int32_t H, int32_t W, int32_t diagonals, int64_t* edge_index, void* stream_) {
+  GNC_REQUIRE(H >= 1 && W >= 1 && (int64_t)H * W < INT32_MAX, "gnc_grid_edges_i64: bad grid %d x %d", H, W);
+  const int64_t E = gnc_grid_num_edges(H, W, diagonals);
+  if (E == 0) return GNC_OK;
+  GNC_REQUIRE(edge_index, "gnc_grid_edges_i64: null output");
+  grid_edges_kernel<<<grid_for(E), gnc::kBlock, 0, (hipStream_t)stream_>>>(H, W, diagonals, E, edge_index);
+  return gnc::check_launch("grid_edges_kernel");
+}
+
+extern "C" int gnc_pixel_nodes_f32(const uint8_t* img, int32_t H, int32_t W, int32_t C, float* x, float* pos,
+                                   void* stream_) {
+  GNC_REQUIRE(H >= 1 && W >= 1 && C >= 1 && img && x && pos, "gnc_pixel_nodes_f32: bad arguments");
+  pixel_nodes_kernel<<<grid_for((int64_t)H * W), gnc::kBlock, 0, (hipStream_t)stream_>>>(img, H, W, C, x, pos);
+  return gnc::check_launch("pixel_nodes_kernel");
+}
+
+extern "C" int gnc_patch_nodes_f32(const uint8_t* img, int32_t H, int32_t W, int32_t C, int32_t patch, float* x,
+                                   float* pos, void* stream_) {
+  GNC_REQUIRE(H >= 1 && W >= 1 && C >= 1 && patch >= 1 && patch <= H && patch <= W && img && x && pos,
+              "gnc_patch_nodes_f32: bad arguments");
+  patch_nodes_kernel<<<grid_for((int64_t)(H / patch) * (W / patch) * C), gnc::kBlock, 0, (hipStream_t)stream_>>>(
+      img, H, W, C, patch, x, pos);
+  return gnc::check_launch("patch_nodes_kernel");
+}
+
+extern "C" size_t gnc_rag_workspace_bytes(int32_t H, int32_t W) {
+  if (H < 1 || W < 1 || (int64_t)H * W >= (1 << 28)) {
+    gnc::set_error("gnc_rag_workspace_bytes: image %d x %d out of range", H, W);
+    return 0;
+  }
+  const int64_t n = (int64_t)H * W;
+  return 2 * align_up((size_t)(n + 1) * 4) + align_up((size_t)n * 4) + align_up((size_t)n * 12) + 4 * align_up((size_t)n * 16) +
+         align_up(4) + align_up(rag_prim_bytes(n)) + kAlign;
+}
+
+extern "C" int gnc_rag_build(const int32_t* labels, const uint8_t* img, int32_t H, int32_t W, float* x, float* pos,
+                             int64_t* edge_index, int64_t ld_edges, int32_t* counts, void* workspace,
+                             size_t workspace_bytes, void* stream_) {
+  GNC_REQUIRE(H >= 1 && W >= 1 && (int64_t)H * W < (1 << 28), "gnc_rag_build: image %d x %d out of range", H, W);
+  GNC_REQUIRE(labels && img && x && pos && edge_index && counts && workspace, "gnc_rag_build: null pointer");
+  const int64_t n = (int64_t)H * W;
+  GNC_REQUIRE(ld_edges >= 4 * n, "gnc_rag_build: edge_index needs room for 4*H*W directed edges per row");
+  hipStream_t stream = (hipStream_t)stream_;
+  RagWs w;
+  if (!carve(workspace, workspace_bytes, n, &w)) {
+    gnc::set_error("gnc_rag_build: workspace too small");
+    return GNC_ERR_WORKSPACE;
+  }
+  int rc = gnc::check_hip(hipMemsetAsync(w.present, 0, (size_t)(n + 1) * 4, stream), "memset present");
+  if (!rc) rc = gnc::check_hip(hipMemsetAsync(w.cnt, 0, (size_t)n * 4, stream), "memset cnt");
+  if (!rc) rc = gnc::check_hip(hipMemsetAsync(w.sum_rgb, 0, (size_t)n * 12, stream), "memset rgb");
+  if (!rc) rc = gnc::check_hip(hipMemsetAsync(w.sum_yx, 0, (size_t)n * 16, stream), "memset yx");
+  if (!rc) rc = gnc::check_hip(hipMemsetAsync(counts, 0, 3 * sizeof(int32_t), stream), "memset counts");
+  if (rc) return rc;
+  rag_mark<<<grid_for(n), gnc::kBlock, 0, stream>>>(labels, n, w.present, counts + 2);
+  if ((rc = gnc::check_launch("rag_mark"))) return rc;
+  size_t pb = w.prim_bytes;
+  rc = gnc::check_hip(rocprim::exclusive_scan(w.prim_tmp, pb, (const int32_t*)w.present, w.rank, 0, (size_t)(n + 1),
+                                              rocprim::plus<int32_t>(), stream),
+                      "rocprim::exclusive_scan");
+  if (rc) return rc;
+  rag_accumulate<<<grid_for(n), gnc::kBlock, 0, stream>>>(labels, img, H, W, w.rank, w.cnt, w.sum_rgb, w.sum_yx, w.keys);
+  if ((rc = gnc::check_launch("rag_accumulate"))) return rc;
+  rag_nodes<<<grid_for(n), gnc::kBlock, 0, stream>>>(w.rank, n, w.cnt, w.sum_rgb, w.sum_yx, x, pos);
+  if ((rc = gnc::check_launch("rag_nodes"))) return rc;
+  pb = w.prim_bytes;
+  rc = gnc::check_hip(rocprim::radix_sort_keys(w.prim_tmp, pb, (const uint64_t*)w.keys, w.sorted, (size_t)(2 * n), 0, 64, stream),
+                      "rocprim::radix_sort_keys");
+  if (rc) return rc;
+  pb = w.prim_bytes;
+  rc = gnc::check_hip(rocprim::unique(w.prim_tmp, pb, (const uint64_t*)w.sorted, w.uniq, w.nuniq, (size_t)(2 * n),
+                                      rocprim::equal_to<uint64_t>(), stream),
+                      "rocprim::unique");
+  if (rc) return rc;
+  rag_edges<<<grid_for(2 * n), gnc::kBlock, 0, stream>>>(w.uniq, w.nuniq, w.rank, n, edge_index, ld_edges, counts);
+  return gnc::check_launch("rag_edges");
+}

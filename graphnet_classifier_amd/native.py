@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 GNC_MAX_SEGMENTS = 4
 GNC_MAX_LINEAR = 8
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 ACTIVATIONS = {  # nn.<Name> accepted by the reference's MLP(activation=...) (models/MLP.py:21)
     "ReLU": 0, "Identity": 1, "Tanh": 2, "Sigmoid": 3, "SiLU": 4, "GELU": 5, "LeakyReLU": 6, "ELU": 7,
@@ -44,6 +44,13 @@ _SIGNATURES = {
     "gnc_mlp_backward_f32": (c_int32, [c_void_p, c_void_p]),
     "gnc_xty_partials": (c_int32, [c_int64]),
     "gnc_xty_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, c_void_p, c_int32, c_void_p]),
+    "gnc_grid_num_edges": (c_int64, [c_int32, c_int32, c_int32]),
+    "gnc_grid_edges_i64": (c_int32, [c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "gnc_pixel_nodes_f32": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "gnc_patch_nodes_f32": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "gnc_rag_workspace_bytes": (c_size_t, [c_int32, c_int32]),
+    "gnc_rag_build": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
+                                c_void_p, c_size_t, c_void_p]),
     "gnc_colsum_pair_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_int32, c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

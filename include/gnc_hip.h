@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GNC_ABI_VERSION 5
+#define GNC_ABI_VERSION 6
 
 enum {
   GNC_OK = 0,
@@ -210,6 +210,31 @@ int gnc_xty_f32(const float* A, int64_t lda, const float* B, int64_t ldb, int64_
                 float* partial, int32_t num_partials, void* stream);
 int gnc_colsum_pair_f32(const float* G, int64_t ldg, const float* Y, int64_t ldy, int64_t rows, int32_t width,
                         float* partial, int32_t num_partials, void* stream);
+
+/* ---- graph construction on the device ---------------------------
+ * Inputs: an already resized uint8 RGB image [H, W, C] in HBM.  Outputs: the tensors
+ * utils/dataloader.py:49-51 builds (x, pos float32; edge_index int64 [2, E] row-major), in the
+ * reference's node and edge order.
+ *
+ * gnc_grid_edges_i64   utils/image_to_graph/image_to_graph_optimized.py:7-39 (one-directional 4-neighbour
+ *                      grid, optional two diagonal families); E = gnc_grid_num_edges().
+ * gnc_pixel_nodes_f32  optimized.py:73-79: x = raw pixel values, pos = (row, col).
+ * gnc_patch_nodes_f32  image_to_graph_patch.py:30-47: mean colour and integer centre per patch.
+ * gnc_rag_build        image_to_graph_superpixel.py:36-71 after SLIC: `labels` [H, W] int32 in [0, H*W);
+ *                      x [<=H*W, 3] mean of img/255 per label, pos = centroid (y, x), labels compacted in
+ *                      ascending order (np.unique); edge_index rows have leading dimension ld_edges >=
+ *                      4*H*W; counts[0] = segments, counts[1] = directed edges, counts[2] = 1 if a label
+ *                      was out of range.
+ */
+int64_t gnc_grid_num_edges(int32_t H, int32_t W, int32_t diagonals);
+int gnc_grid_edges_i64(int32_t H, int32_t W, int32_t diagonals, int64_t* edge_index, void* stream);
+int gnc_pixel_nodes_f32(const uint8_t* img, int32_t H, int32_t W, int32_t C, float* x, float* pos, void* stream);
+int gnc_patch_nodes_f32(const uint8_t* img, int32_t H, int32_t W, int32_t C, int32_t patch, float* x, float* pos,
+                        void* stream);
+size_t gnc_rag_workspace_bytes(int32_t H, int32_t W);
+int gnc_rag_build(const int32_t* labels, const uint8_t* img, int32_t H, int32_t W, float* x, float* pos,
+                  int64_t* edge_index, int64_t ld_edges, int32_t* counts, void* workspace, size_t workspace_bytes,
+                  void* stream);
 
 #ifdef __cplusplus
 }

@@ -209,5 +209,29 @@ def main():
     _save("g6_grid_edges.npz", **arrays)
 
 
+def image_graphs():
+    """G7: the reference's own pixel and patch builders on shipped images (the formats of SURVEY 2.3)."""
+    sys.path.insert(0, REF)
+    from PIL import Image
+    from utils.image_to_graph.image_to_graph_optimized import image_to_graph_pixel_optimized
+    from utils.image_to_graph.image_to_graph_patch import image_to_graph_patch
+    arrays = {}
+    for tag, path, r in (("muffin32", "static/muffin/img_4_880_32.jpg", 32), ("chihuahua64", "static/chihuahua/img_4_799_64.jpg", 64)):
+        img = Image.open(os.path.join(REF, path)).convert("RGB").resize((r, r))
+        arrays[f"{tag}/img"] = np.array(img)
+        for diag in (False, True):
+            x, pos, ei = image_to_graph_pixel_optimized(img, resize_value=r, diagonals=diag)
+            d = "diag" if diag else "nodiag"
+            arrays[f"{tag}/pixel_{d}/x"] = np.asarray(x).astype(np.float32)      # dataloader.py:49
+            arrays[f"{tag}/pixel_{d}/pos"] = np.asarray(pos).astype(np.float32)  # :50
+            arrays[f"{tag}/pixel_{d}/edge_index"] = np.asarray(ei).astype(np.int64)
+        x, pos, ei = image_to_graph_patch(img, resize_value=r, patch_size=8)
+        arrays[f"{tag}/patch/x"] = np.asarray(x, dtype=np.float64).astype(np.float32)
+        arrays[f"{tag}/patch/pos"] = np.asarray(pos).astype(np.float32)
+        arrays[f"{tag}/patch/edge_index"] = np.asarray(ei).astype(np.int64)
+    _save("g7_image_graphs.npz", **arrays)
+
+
 if __name__ == "__main__":
     main()
+    image_graphs()

@@ -120,3 +120,31 @@ def test_edge_features_l1():
     ei = torch.tensor([[0, 1, 2], [1, 2, 0]])
     e = O.edge_features(pos, ei)
     assert torch.equal(e, torch.tensor([[1.0, 3.0, 4.0], [3.0, -4.0, 7.0], [-4.0, 1.0, 5.0]]))
+
+
+def test_g7_pixel_and_patch_builders():
+    from oracle import image_graph_oracle as IO
+    g = load_golden("g7_image_graphs.npz")
+    for tag in ("muffin32", "chihuahua64"):
+        img = g[f"{tag}/img"]
+        for diag in (False, True):
+            d = "diag" if diag else "nodiag"
+            x, pos, ei = IO.pixel_graph(img, diag)
+            assert np.array_equal(x, g[f"{tag}/pixel_{d}/x"]) and np.array_equal(pos, g[f"{tag}/pixel_{d}/pos"])
+            assert np.array_equal(ei, g[f"{tag}/pixel_{d}/edge_index"])
+        x, pos, ei = IO.patch_graph(img, 8)
+        assert np.array_equal(x, g[f"{tag}/patch/x"]) and np.array_equal(pos, g[f"{tag}/patch/pos"])
+        assert np.array_equal(ei, g[f"{tag}/patch/edge_index"])
+
+
+def test_superpixel_builder_restatement_on_a_label_image():
+    from oracle import image_graph_oracle as IO
+    seg = np.array([[0, 0, 1, 1], [0, 2, 2, 1], [3, 3, 2, 5], [3, 3, 5, 5]])  # label 4 unused: np.unique compacts
+    img = (np.arange(48).reshape(4, 4, 3) * 5).astype(np.uint8)
+    x, pos, ei = IO.superpixel_graph_from_labels(img, seg)
+    assert x.shape == (5, 3) and pos.shape == (5, 2)
+    pairs = {(int(a), int(b)) for a, b in ei.T}
+    und = [(0, 1), (0, 2), (0, 3), (1, 2), (1, 4), (2, 3), (2, 4), (3, 4)]
+    assert pairs == set(und) | {(b, a) for a, b in und}
+    assert ei[:, 0].tolist() == [0, 1] and ei[:, 1].tolist() == [1, 0]  # [i,j],[j,i] interleaved, lexicographic
+    assert np.allclose(pos[0], [1 / 3, 1 / 3]) and np.allclose(x[0], img[seg == 0].mean(0) / 255.0)

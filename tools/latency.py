@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Per-graph latency of the default model (main.py:72: D=128, 3 blocks) the way the reference drives it:
+one graph per call, host tensors in, logits out (utils/train_model.py:35-45)."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from graphnet_classifier_amd import synthetic  # noqa: E402
+from graphnet_classifier_amd.GNN import CombinedModel, GraphNet  # noqa: E402
+from oracle import graphnet_oracle as O  # noqa: E402  (only for the grid topology of the pixel graph)
+
+torch.manual_seed(0)
+cases = {}
+ei = torch.from_numpy(O.grid_edge_index(32, 32))
+rr, cc = np.meshgrid(np.arange(32), np.arange(32), indexing="ij")
+cases["pixel R=32 (N=1024, E=1984)"] = (torch.rand(1024, 3) * 255, torch.from_numpy(np.stack([rr.ravel(), cc.ravel()], 1).astype(np.float32)), ei)
+b = synthetic.superpixel_like_graphs(1, seed=1000, shapes=((12, 12),))
+cases["superpixel-like (N=144, E~790)"] = (b.x, b.pos, b.edge_index)
+for name, (x, pos, ei) in cases.items():
+    model = CombinedModel(GraphNet(num_local_features=3, space_dim=2, out_channels=1, n_blocks=3), num_nodes=x.size(0), classes=2)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    crit = torch.nn.CrossEntropyLoss()
+    label = torch.tensor(1)
+    for mode in ("forward", "train"):
+        ts = []
+        for it in range(30):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            if mode == "forward":
+                with torch.no_grad():
+                    logits = model((x, pos, ei))
+            else:
+                logits = model((x, pos, ei))
+                loss = crit(logits, label)
+                opt.zero_grad(); loss.backward(); opt.step()
+                _ = loss.item()
+            torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+        print(f"{name:36s} {mode:8s} median {1e3*np.median(ts[5:]):7.3f} ms  min {1e3*np.min(ts[5:]):7.3f} ms", flush=True)
