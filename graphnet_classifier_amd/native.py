@@ -142,7 +142,9 @@ def _rowmajor(t: torch.Tensor) -> torch.Tensor:
 
 
 def _ld(t: torch.Tensor) -> int:
-    return t.stride(0) if t.size(0) > 1 else max(t.size(1), 1)
+    if t.size(0) > 1 or t.stride(0) >= t.size(1):
+        return max(t.stride(0), 1)
+    return max(t.size(1), 1)  # a single row whose stride says nothing
 
 
 # --------------------------------------------------------------------------- kernel timers
@@ -314,7 +316,7 @@ def _vector_rows(t: torch.Tensor, cache: bool = False) -> torch.Tensor:
     aligned base.  Anything else (the reference's 3-column inputs and [H, 3] first-layer weights) is
     copied once into a zero-padded buffer and handed over as a column slice of it; small weights are
     cached by identity and version (an optimizer step bumps the version)."""
-    if t.data_ptr() % 16 == 0 and (t.size(0) <= 1 or t.stride(0) % 4 == 0):
+    if t.data_ptr() % 16 == 0 and _ld(t) % 4 == 0:
         return t
     key = (t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride())) if cache else None
     if key is not None and key in _padded_cache:
