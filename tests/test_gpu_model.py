@@ -274,6 +274,24 @@ def test_degenerate_graphs(G, case):
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m.parameters())
 
 
+def test_captured_forward_replays_bit_identically(G):
+    """hipGraph replay of the forward for a fixed pixel-grid topology equals the eager forward, for new inputs."""
+    rng = np.random.default_rng(0)
+    ei = torch.from_numpy(O.grid_edge_index(16, 16))
+    rr, cc = np.meshgrid(np.arange(16), np.arange(16), indexing="ij")
+    pos = torch.from_numpy(np.stack([rr.ravel(), cc.ravel()], 1).astype(np.float32))
+    torch.manual_seed(4)
+    m = G.CombinedModel(G.GraphNet(num_local_features=3, space_dim=2, out_channels=1, n_blocks=3), num_nodes=256, classes=2)
+    m.eval()
+    x0 = torch.from_numpy((rng.random((256, 3)) * 255).astype(np.float32))
+    cap = G.CapturedForward(m, x0, pos, ei)
+    for _ in range(3):
+        x = torch.from_numpy((rng.random((256, 3)) * 255).astype(np.float32))
+        with torch.no_grad():
+            eager = m((x.to(DEV), pos.to(DEV), ei.to(DEV)))
+        assert torch.equal(cap(x).clone(), eager)
+
+
 def test_forward_on_cpu_module_fails_loudly(G):
     m = G.GraphNet(**{"n_blocks": 1}).to("cpu")
     with pytest.raises(RuntimeError, match="no CPU fallback"):

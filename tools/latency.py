@@ -25,6 +25,16 @@ for name, (x, pos, ei) in cases.items():
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     crit = torch.nn.CrossEntropyLoss()
     label = torch.tensor(1)
+    from graphnet_classifier_amd.GNN import CapturedForward
+    cap = CapturedForward(model.eval(), x, pos, ei)
+    xd = x.to("cuda:0")
+    ts = []
+    for it in range(50):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        out = cap(xd)
+        torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    print(f"{name:36s} hipGraph replay (device input) median {1e3*np.median(ts[5:]):7.3f} ms", flush=True)
+    model.train()
     for mode in ("forward", "train"):
         ts = []
         for it in range(30):
