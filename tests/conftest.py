@@ -18,6 +18,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (runs the HIP kernels through the C-ABI)")
 
 
+def pytest_sessionstart(session):
+    """The shared library is a build artefact (git-ignored).  In a fresh checkout build it once, exactly as
+    __graft_entry__.build() does (hipcc cross-compiles gfx950 without a GPU), so that the C-ABI tests have
+    something to load; on the GPU box the prebuilt file travels with the snapshot and nothing happens."""
+    lib = os.path.join(ROOT, "graphnet_classifier_amd", "libgnc_hip.so")
+    if not os.path.exists(lib):
+        import subprocess
+        subprocess.run(["make", "-j", "4", "-C", os.path.join(ROOT, "graphnet_classifier_amd", "csrc")], check=True,
+                       stdout=subprocess.DEVNULL)
+
+
 def pytest_collection_modifyitems(config, items):
     """GPU tests fail loudly on a GPU-less host only when explicitly selected; when the
     whole suite is run without -m they are skipped there."""
