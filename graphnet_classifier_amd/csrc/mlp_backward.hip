@@ -324,6 +324,387 @@ __global__ __launch_bounds__(BNT) void mlp_backward_data_kernel(const gnc_mlp_de
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Streamed variant of the data kernel for widths 65..128: the weights do not fit in LDS, so the chunk
+// sequence of a tile - forward chunks, then the SAME [features][64 k] chunks again in reverse layer order
+// for the transposed products - streams through the double buffer of mlp_stream.hip (registers ->
+// alternate LDS buffer -> one barrier per chunk).  4 waves x 512 registers: the chain needs four
+// accumulator sets of 64 registers (hid, next, g, da) at width 128.
+// ---------------------------------------------------------------------------------------------------
+constexpr int SB_MAX_STEPS = 16;
+constexpr int SB_MAX_WCHUNKS = 64;
+
+struct BwdPlan {
+  int num_steps;     // first-Linear staging steps per tile
+  int num_wchunks;   // weight chunks per tile (forward + backward)
+  struct { short seg, seg2, c0, add; } step[SB_MAX_STEPS];
+  struct { short layer, kbase, klimit, pad; } wc[SB_MAX_WCHUNKS];
+};
+
+// dst[2c], dst[2c+1] += (columns [64c, 64c+64) of W)^T * src   (chunk buffer = [n][64 k] of those columns)
+template <int TI, int TO, int C>
+__device__ __forceinline__ void mma_transposed_chunk(f32x16 (&dst)[TO], const f32x16 (&src)[TI], const float* wbuf, int i,
+                                                     int h) {
+#pragma unroll
+  for (int t = 0; t < TI; ++t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if constexpr (2 * C < TO) dst[2 * C] = mfma(wbuf[n * LDSW + i], src[t][r], dst[2 * C]);
+      if constexpr (2 * C + 1 < TO) dst[2 * C + 1] = mfma(wbuf[n * LDSW + 32 + i], src[t][r], dst[2 * C + 1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int HT>
+__global__ __launch_bounds__(256) void mlp_backward_stream_kernel(const gnc_mlp_desc_t d, const BwdArgs b, const BwdPlan pl,
+                                                                  const int num_tiles) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int WAVES = 4;
+  constexpr int NT = WAVES * 64;
+  constexpr int CH = HT * 32 * LDSW;
+  constexpr int PSTRIDE = HT * 32;
+  constexpr int RPP = NT / 16;
+  constexpr int NW = (HT * 32) / RPP;
+  constexpr int NCH = (HT + 1) / 2;  // 64-column chunks of a full-width tile
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 31;
+  const int h = lane >> 5;
+  const int c4 = lane & 15;
+  const int rs = lane >> 4;
+  const int wc4 = tid & 15;
+  const int wr0 = tid >> 4;
+  const int L = d.num_linear;
+  const int out_dim = d.out_dim[L - 1];
+  const int rows = (int)d.rows;
+  float* wbuf = lds;
+  float* pbuf = lds + 2 * CH;
+  float* abuf = pbuf + (L + 2) * PSTRIDE + wave * RPW * LDSW;
+
+  stage_params<NT>(pbuf, d, PSTRIDE, tid);
+
+  auto wload = [&](f32x4 (&wr)[NW], int q) {
+    const int layer = pl.wc[q].layer;
+    const float* W = d.weight[layer];
+    const int ldw = ldw_of(d, layer);
+    const int nrows = d.out_dim[layer];
+    const int klimit = pl.wc[q].klimit;
+    const int col = pl.wc[q].kbase + wc4 * 4;
+    const int colc = col < klimit ? col : pl.wc[q].kbase;
+#pragma unroll
+    for (int p = 0; p < NW; ++p) {
+      const int n = p * RPP + wr0;
+      const int nc = n < nrows ? n : nrows - 1;
+      f32x4 v = *reinterpret_cast<const f32x4*>(W + (int64_t)nc * ldw + colc);
+      const bool rowok = n < nrows;
+      v.x = (rowok && col + 0 < klimit) ? v.x : 0.f; v.y = (rowok && col + 1 < klimit) ? v.y : 0.f;
+      v.z = (rowok && col + 2 < klimit) ? v.z : 0.f; v.w = (rowok && col + 3 < klimit) ? v.w : 0.f;
+      wr[p] = v;
+    }
+  };
+  auto wstore = [&](const f32x4 (&wr)[NW], float* buf) {
+#pragma unroll
+    for (int p = 0; p < NW; ++p) *reinterpret_cast<f32x4*>(buf + (p * RPP + wr0) * LDSW + wc4 * 4) = wr[p];
+  };
+  auto load_idx = [&](int row0, int s) -> int {
+    int r = row0 + (lane & 31);
+    r = r < rows ? r : rows - 1;
+    const int32_t* ip = d.seg[s].index;
+    return ip ? ip[r] : r;
+  };
+  auto load_rows = [&](f32x4 (&pre)[NP], const float* base, int ld, int c0, int idxv) {
+    const int col = c0 + c4 * 4 < ld ? c0 + c4 * 4 : 0;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int tr = __shfl(idxv, p * 4 + rs, 64);
+      pre[p] = *reinterpret_cast<const f32x4*>(base + (int64_t)tr * ld + col);
+    }
+  };
+  auto stage = [&](const f32x4 (&pre)[NP], int c0, int width) {
+    compiler_lds_barrier();
+    const int c = c0 + c4 * 4;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      f32x4 v = pre[p];
+      v.x = c + 0 < width ? v.x : 0.f; v.y = c + 1 < width ? v.y : 0.f;
+      v.z = c + 2 < width ? v.z : 0.f; v.w = c + 3 < width ? v.w : 0.f;
+      *reinterpret_cast<f32x4*>(abuf + (p * 4 + rs) * LDSW + c4 * 4) = v;
+    }
+    compiler_lds_barrier();
+  };
+  // 64 columns [64*cc, +64) of `acc` -> rows of dst (columns < width)
+  auto emit_chunk = [&](float* dst, int ld, int width, int row0, int cc) {
+    compiler_lds_barrier();
+    const int col = cc * KC + c4 * 4;
+    const bool vec = (width % 4 == 0) && (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int r = row0 + p * 4 + rs;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(abuf + (p * 4 + rs) * LDSW + c4 * 4);
+      store_row_piece(dst + (int64_t)(r < rows ? r : rows - 1) * ld, col, v, r < rows && col < width, width, vec);
+    }
+    compiler_lds_barrier();
+  };
+  auto emit = [&](const f32x16 (&acc)[HT], float* dst, int ld, int width, int row0) {
+#pragma unroll
+    for (int cc = 0; cc < NCH; ++cc) {
+      if (cc * KC < width) {
+        compiler_lds_barrier();
+        switch (cc) {
+          case 0: chunk_to_lds<HT, 0>(acc, abuf, i, h); break;
+          case 1: chunk_to_lds<HT, 2>(acc, abuf, i, h); break;
+          case 2: chunk_to_lds<HT, 4>(acc, abuf, i, h); break;
+          default: chunk_to_lds<HT, 6>(acc, abuf, i, h); break;
+        }
+        emit_chunk(dst, ld, width, row0, cc);
+      }
+    }
+  };
+
+  f32x4 wreg[NW];
+  wload(wreg, 0);
+  wstore(wreg, wbuf);
+  __syncthreads();
+  int gq = 0;
+  int q = 0;  // chunk index inside the tile's sequence
+  auto prefetch_next_chunk = [&]() { wload(wreg, q + 1 < pl.num_wchunks ? q + 1 : 0); };
+  auto publish_next_chunk = [&]() {
+    wstore(wreg, wbuf + ((gq + 1) & 1) * CH);
+    __syncthreads();
+    ++gq;
+    q = q + 1 < pl.num_wchunks ? q + 1 : 0;
+  };
+  auto cur_chunk = [&]() -> const float* { return wbuf + (gq & 1) * CH; };
+
+  for (int tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
+    const int row0 = (tile * WAVES + wave) * RPW;
+
+    // ------------------------------------------------------------------ forward recompute
+    f32x16 hid[HT];
+    init_bias<HT>(hid, pbuf, h);
+    for (int st = 0; st < pl.num_steps; ++st) {
+      const int s = pl.step[st].seg, s2 = pl.step[st].seg2, c0 = pl.step[st].c0;
+      f32x4 pre[NP];
+      load_rows(pre, d.seg[s].ptr, d.seg[s].ld, c0, load_idx(row0, s));
+      if (s2 >= 0) {
+        f32x4 pre2[NP];
+        load_rows(pre2, d.seg[s2].ptr, d.seg[s2].ld, c0, load_idx(row0, s2));
+#pragma unroll
+        for (int p = 0; p < NP; ++p) pre[p] += pre2[p];
+      }
+      stage(pre, c0, d.seg[s].width);
+      if (pl.step[st].add) {
+        switch (c0 >> 6) {
+          case 0: add_chunk_from_lds<HT, 0>(hid, abuf, i, h); break;
+          case 1: add_chunk_from_lds<HT, 2>(hid, abuf, i, h); break;
+          case 2: add_chunk_from_lds<HT, 4>(hid, abuf, i, h); break;
+          default: add_chunk_from_lds<HT, 6>(hid, abuf, i, h); break;
+        }
+      } else {
+        prefetch_next_chunk();
+        const int kc = d.seg[s].width - c0 < KC ? d.seg[s].width - c0 : KC;
+        mma_chunk_from_lds<HT>(hid, abuf, cur_chunk(), (kc + 7) >> 3, i, h);
+        publish_next_chunk();
+      }
+    }
+    unsigned mask[GNC_MAX_LINEAR - 1][NCH];  // ReLU masks: 32 bits per 64-column chunk and layer
+    auto relu_mask = [&](f32x16 (&acc)[HT], int l) {
+#pragma unroll
+      for (int cc = 0; cc < NCH; ++cc) {
+        unsigned m = 0;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            if (2 * cc + tt < HT) {
+              const bool pos = acc[2 * cc + tt < HT ? 2 * cc + tt : 0][r] > 0.f;
+              m |= pos ? (1u << (16 * tt + r)) : 0u;
+              acc[2 * cc + tt < HT ? 2 * cc + tt : 0][r] = pos ? acc[2 * cc + tt < HT ? 2 * cc + tt : 0][r] : 0.f;
+            }
+          }
+        mask[l][cc] = m;
+      }
+    };
+    auto apply_mask_l = [&](f32x16 (&acc)[HT], int l) {
+#pragma unroll
+      for (int cc = 0; cc < NCH; ++cc)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (2 * cc + tt < HT) {
+              const int t = 2 * cc + tt < HT ? 2 * cc + tt : 0;
+              acc[t][r] = (mask[l][cc] >> (16 * tt + r)) & 1u ? acc[t][r] : 0.f;
+            }
+    };
+    relu_mask(hid, 0);
+    emit(hid, b.act[0], d.out_dim[0], d.out_dim[0], row0);
+#pragma unroll
+    for (int l = 1; l < GNC_MAX_LINEAR - 1; ++l) {
+      if (l < L - 1) {
+        f32x16 nxt[HT];
+        init_bias<HT>(nxt, pbuf + l * PSTRIDE, h);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          if (c * KC < d.in_dim[l]) {
+            prefetch_next_chunk();
+            mma_chunk_from_regs<HT, HT>(nxt, hid, cur_chunk(), c, d.in_dim[l], i, h);
+            publish_next_chunk();
+          }
+        }
+        relu_mask(nxt, l);
+#pragma unroll
+        for (int t = 0; t < HT; ++t) hid[t] = nxt[t];
+        emit(hid, b.act[l], d.out_dim[l], d.out_dim[l], row0);
+      }
+    }
+
+    // ------------------------------------------------------------------ grad_out tile, LayerNorm backward
+    f32x16 g[HT];
+#pragma unroll
+    for (int cc = 0; cc < NCH; ++cc) {
+      if (cc * KC < out_dim) {
+        f32x4 pre[NP];
+        int r = row0 + (lane & 31);
+        r = r < rows ? r : rows - 1;
+        load_rows(pre, b.grad_out, b.ld_grad_out, cc * KC, r);
+        stage(pre, cc * KC, out_dim);
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+          if (2 * cc + tt < HT) {
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+              const f32x4 v = *reinterpret_cast<const f32x4*>(abuf + i * LDSW + 32 * tt + 8 * qq + 4 * h);
+              const int t = 2 * cc + tt < HT ? 2 * cc + tt : 0;
+              g[t][4 * qq + 0] = v.x; g[t][4 * qq + 1] = v.y; g[t][4 * qq + 2] = v.z; g[t][4 * qq + 3] = v.w;
+            }
+          }
+        compiler_lds_barrier();
+      } else {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+          if (2 * cc + tt < HT)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) g[2 * cc + tt < HT ? 2 * cc + tt : 0][r] = 0.f;
+      }
+    }
+    if (d.ln_gamma) {
+      f32x16 y[HT];
+      init_bias<HT>(y, pbuf + (L - 1) * PSTRIDE, h);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        if (c * KC < d.in_dim[L - 1]) {
+          prefetch_next_chunk();
+          mma_chunk_from_regs<HT, HT>(y, hid, cur_chunk(), c, d.in_dim[L - 1], i, h);
+          publish_next_chunk();
+        }
+      }
+      float s = 0.f;
+#pragma unroll
+      for (int t = 0; t < HT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += (feat_of(t, r, h) < out_dim) ? y[t][r] : 0.f;
+      s += __shfl_xor(s, 32, 64);
+      const float mean = s / (float)out_dim;
+      float v = 0.f;
+#pragma unroll
+      for (int t = 0; t < HT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float dl = y[t][r] - mean;
+          v += (feat_of(t, r, h) < out_dim) ? dl * dl : 0.f;
+        }
+      v += __shfl_xor(v, 32, 64);
+      const float rstd = 1.f / sqrtf(v / (float)out_dim + d.ln_eps);
+      const float* pg = pbuf + L * PSTRIDE;
+      float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+      for (int t = 0; t < HT; ++t)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+          const f32x4 gm = *reinterpret_cast<const f32x4*>(pg + 32 * t + 8 * qq + 4 * h);
+          const float gmv[4] = {gm.x, gm.y, gm.z, gm.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int r = 4 * qq + k;
+            const bool ok = feat_of(t, r, h) < out_dim;
+            const float yh = ok ? (y[t][r] - mean) * rstd : 0.f;
+            const float gg = (ok ? g[t][r] : 0.f) * gmv[k];
+            m1 += gg;
+            m2 += gg * yh;
+            y[t][r] = yh;
+            g[t][r] = gg;
+          }
+        }
+      emit(y, b.yhat, out_dim, out_dim, row0);
+      m1 += __shfl_xor(m1, 32, 64);
+      m2 += __shfl_xor(m2, 32, 64);
+      m1 /= (float)out_dim;
+      m2 /= (float)out_dim;
+#pragma unroll
+      for (int t = 0; t < HT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          g[t][r] = (feat_of(t, r, h) < out_dim) ? rstd * (g[t][r] - m1 - y[t][r] * m2) : 0.f;
+    } else {
+#pragma unroll
+      for (int t = 0; t < HT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[t][r] = (feat_of(t, r, h) < out_dim) ? g[t][r] : 0.f;
+    }
+    emit(g, b.dz[L - 1], out_dim, out_dim, row0);
+
+    // ------------------------------------------------------------------ back through the Linear layers
+#pragma unroll
+    for (int l = GNC_MAX_LINEAR - 2; l >= 0; --l) {
+      if (l < L - 1) {
+        f32x16 da[HT];
+        zero_tiles<HT>(da);
+        // chunks of W_{l+1} by 64 input columns: chunk c yields da tiles 2c, 2c+1
+        if (0 * KC < d.in_dim[l + 1]) { prefetch_next_chunk(); mma_transposed_chunk<HT, HT, 0>(da, g, cur_chunk(), i, h); publish_next_chunk(); }
+        if constexpr (NCH > 1) if (1 * KC < d.in_dim[l + 1]) { prefetch_next_chunk(); mma_transposed_chunk<HT, HT, 1>(da, g, cur_chunk(), i, h); publish_next_chunk(); }
+        if constexpr (NCH > 2) if (2 * KC < d.in_dim[l + 1]) { prefetch_next_chunk(); mma_transposed_chunk<HT, HT, 2>(da, g, cur_chunk(), i, h); publish_next_chunk(); }
+        if constexpr (NCH > 3) if (3 * KC < d.in_dim[l + 1]) { prefetch_next_chunk(); mma_transposed_chunk<HT, HT, 3>(da, g, cur_chunk(), i, h); publish_next_chunk(); }
+        apply_mask_l(da, l);
+#pragma unroll
+        for (int t = 0; t < HT; ++t) g[t] = da[t];
+        emit(g, b.dz[l], d.out_dim[l], d.out_dim[l], row0);
+      }
+    }
+    if (b.dx) {  // one 64-column slab of dx per MATMUL step, in step order (= the order of the plan's last chunks)
+      for (int st = 0; st < pl.num_steps; ++st) {
+        if (pl.step[st].add) continue;
+        const int s = pl.step[st].seg, c0 = pl.step[st].c0;
+        f32x16 dxs[2];
+        zero_tiles<2>(dxs);
+        prefetch_next_chunk();
+        mma_transposed_chunk<HT, 2, 0>(dxs, g, cur_chunk(), i, h);
+        publish_next_chunk();
+        compiler_lds_barrier();
+        chunk_to_lds<2, 0>(dxs, abuf, i, h);
+        // columns c0 .. c0+63 of segment s -> dx[:, wcol_s + c0 ...]
+        {
+          compiler_lds_barrier();
+          float* dst = b.dx + d.seg[s].wcol + c0;
+          const int width = d.seg[s].width - c0 < KC ? d.seg[s].width - c0 : KC;
+          const int col = c4 * 4;
+          const bool vec = (width % 4 == 0) && (b.ld_dx % 4 == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0);
+#pragma unroll
+          for (int p = 0; p < NP; ++p) {
+            const int r = row0 + p * 4 + rs;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(abuf + (p * 4 + rs) * LDSW + col);
+            store_row_piece(dst + (int64_t)(r < rows ? r : rows - 1) * b.ld_dx, col, v, r < rows && col < width, width, vec);
+          }
+          compiler_lds_barrier();
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // xty: C[M, K] = sum over rows of A[row, 0:M]^T B[row, 0:K];  colsum[M] = sum over rows of A[row, 0:M]
 // (dW = dz^T a, db = colsum(dz)).  M, K <= 64.  Each wave streams 32-row tiles with the rows on the MFMA
 // k axis (2 rows per step: lane (i, h) holds A[row 2s+h][32 tA + i] and B[row 2s+h][32 tB + i]: 128-B
@@ -520,6 +901,80 @@ int launch_bwd(const gnc_mlp_desc_t& d, const BwdArgs& b, int total_chunks, size
   return gnc::check_launch("mlp_backward_data_kernel");
 }
 
+// plan of the streamed variant; returns false if the shape is outside it
+bool bwd_stream_plan(const gnc_mlp_desc_t& d, bool want_dx, BwdPlan* pl, int* T_out) {
+  const int L = d.num_linear;
+  if (L < 2 || L > GNC_MAX_LINEAR - 1 || d.activation != GNC_ACT_RELU || d.rows >= INT32_MAX || d.rows < 1) return false;
+  int wmax = 0;
+  for (int l = 0; l < L; ++l) {
+    if (d.out_dim[l] > wmax) wmax = d.out_dim[l];
+    if (l > 0 && d.in_dim[l] > wmax) wmax = d.in_dim[l];
+    if (ldw_of(d, l) % 4 != 0 || !al16(d.weight[l])) return false;
+  }
+  if (wmax > 128) return false;  // four 64-register accumulator sets is what 512 registers hold
+  const int T = tiles_for(wmax);
+  *pl = BwdPlan{};
+  int add_seg[GNC_MAX_SEGMENTS], nadd = 0;
+  for (int s = 0; s < d.num_segments; ++s) {
+    const gnc_mlp_segment_t& g = d.seg[s];
+    if (g.ld % 4 != 0 || !al16(g.ptr)) return false;
+    if (g.mode == GNC_SEG_ADD) { add_seg[nadd++] = s; continue; }
+    if (g.wcol % 4 != 0) return false;
+    for (int c0 = 0; c0 < g.width; c0 += KC) {
+      if (pl->num_steps >= SB_MAX_STEPS || pl->num_wchunks >= SB_MAX_WCHUNKS) return false;
+      pl->step[pl->num_steps++] = {(short)s, (short)-1, (short)c0, (short)0};
+      pl->wc[pl->num_wchunks++] = {(short)0, (short)(g.wcol + c0), (short)(g.wcol + g.width), 0};
+    }
+  }
+  if (pl->num_wchunks == 0) return false;
+  const int mm_chunks = pl->num_wchunks;
+  for (int a = 0; a < nadd; a += 2) {
+    const int s = add_seg[a], s2 = a + 1 < nadd ? add_seg[a + 1] : -1;
+    for (int c0 = 0; c0 < d.seg[s].width; c0 += KC) {
+      if (pl->num_steps >= SB_MAX_STEPS) return false;
+      pl->step[pl->num_steps++] = {(short)s, (short)s2, (short)c0, (short)1};
+    }
+  }
+  auto push_layer = [&](int l) {
+    for (int c = 0; c * KC < d.in_dim[l]; ++c) {
+      if (pl->num_wchunks >= SB_MAX_WCHUNKS) return false;
+      pl->wc[pl->num_wchunks++] = {(short)l, (short)(c * KC), (short)d.in_dim[l], 0};
+    }
+    return true;
+  };
+  for (int l = 1; l < L - 1; ++l)
+    if (!push_layer(l)) return false;          // forward, hidden layers
+  if (d.ln_gamma && !push_layer(L - 1)) return false;  // forward of the last Linear only feeds the LayerNorm statistics
+  for (int l = L - 2; l >= 0; --l)
+    if (!push_layer(l + 1)) return false;      // backward: W_{l+1}^T
+  if (want_dx)
+    for (int k = 0; k < mm_chunks; ++k) {      // dx: the first Linear's chunks again, in step order
+      if (pl->num_wchunks >= SB_MAX_WCHUNKS) return false;
+      pl->wc[pl->num_wchunks] = pl->wc[k];
+      ++pl->num_wchunks;
+    }
+  *T_out = T;
+  return true;
+}
+
+template <int HT>
+int launch_bwd_stream(const gnc_mlp_desc_t& d, const BwdArgs& b, const BwdPlan& pl, hipStream_t stream) {
+  const size_t smem = ((size_t)2 * HT * 32 * LDSW + (size_t)(d.num_linear + 2) * HT * 32 + (size_t)4 * RPW * LDSW) * sizeof(float);
+  if (smem > 160 * 1024) { gnc::set_error("mlp_backward_stream: LDS budget exceeded"); return GNC_ERR_UNSUPPORTED; }
+  static bool attr_set = false;
+  if (!attr_set) {
+    int rc = gnc::check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_backward_stream_kernel<HT>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                            "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    if (rc) return rc;
+    attr_set = true;
+  }
+  const int64_t num_tiles = gnc::ceil_div(d.rows, (int64_t)4 * RPW);
+  const int64_t grid = num_tiles < gnc::kNumCU ? num_tiles : gnc::kNumCU;
+  mlp_backward_stream_kernel<HT><<<dim3((unsigned)grid), dim3(256), smem, stream>>>(d, b, pl, (int)num_tiles);
+  return gnc::check_launch("mlp_backward_stream_kernel");
+}
+
 int bwd_grid(int64_t rows) {
   int64_t grid = gnc::ceil_div(gnc::ceil_div(rows, RPW), BWAVES);
   return (int)(grid > gnc::kNumCU ? gnc::kNumCU : grid);
@@ -533,8 +988,9 @@ extern "C" int gnc_mlp_backward_supported(const gnc_mlp_desc_t* fwd) {
   int rc = validate_desc(fwd, false);
   if (rc) return rc;
   int nmm, nadd, T;
-  if (!bwd_shape(*fwd, &nmm, &nadd, &T)) {
-    gnc::set_error("gnc_mlp_backward: shape outside the HIP backward kernel (needs ReLU, widths <= 64, aligned tables)");
+  BwdPlan pl;
+  if (!bwd_shape(*fwd, &nmm, &nadd, &T) && !bwd_stream_plan(*fwd, true, &pl, &T)) {
+    gnc::set_error("gnc_mlp_backward: shape outside the HIP backward kernels (needs ReLU, widths <= 128, aligned tables)");
     return GNC_ERR_UNSUPPORTED;
   }
   return GNC_OK;
@@ -545,9 +1001,11 @@ extern "C" int gnc_mlp_backward_f32(const gnc_mlp_bwd_desc_t* bd, void* stream_)
   const gnc_mlp_desc_t& d = bd->fwd;
   int rc = validate_desc(&d, false);
   if (rc) return rc;
-  int nmm, nadd, T;
-  if (!bwd_shape(d, &nmm, &nadd, &T)) {
-    gnc::set_error("gnc_mlp_backward_f32: shape outside the HIP backward kernel");
+  int nmm = 0, nadd = 0, T = 0;
+  BwdPlan pl;
+  const bool resident = bwd_shape(d, &nmm, &nadd, &T);
+  if (!resident && !bwd_stream_plan(d, bd->dx != nullptr, &pl, &T)) {
+    gnc::set_error("gnc_mlp_backward_f32: shape outside the HIP backward kernels");
     return GNC_ERR_UNSUPPORTED;
   }
   const int L = d.num_linear;
@@ -569,6 +1027,14 @@ extern "C" int gnc_mlp_backward_f32(const gnc_mlp_bwd_desc_t* bd, void* stream_)
   b.ld_dx = bd->ld_dx;
   b.yhat = d.ln_gamma ? bd->yhat : nullptr;
 
+  if (!resident) {
+    hipStream_t st = (hipStream_t)stream_;
+    switch (T) {
+      case 1: return launch_bwd_stream<1>(d, b, pl, st);
+      case 2: return launch_bwd_stream<2>(d, b, pl, st);
+      default: return launch_bwd_stream<4>(d, b, pl, st);
+    }
+  }
   const int total_chunks = nmm + (L - 1);
   const size_t smem =
       ((size_t)total_chunks * T * 32 * LDSW + (size_t)(L + 2) * T * 32 + (size_t)BWAVES * RPW * LDSW) * sizeof(float);

@@ -40,39 +40,6 @@ struct StreamPlan {
   } wc[MAX_WCHUNKS];
 };
 
-// tiles [T0, T0+2) of the accumulator <-> the 64 staged columns
-template <int T, int TA, int TT>
-__device__ __forceinline__ void add_one_tile_from_lds(f32x16 (&acc)[T], const float* abuf, int i, int h) {
-  if constexpr (TA < T) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(abuf + i * LDSW + 32 * TT + 8 * q + 4 * h);
-      acc[TA][4 * q + 0] += v.x; acc[TA][4 * q + 1] += v.y; acc[TA][4 * q + 2] += v.z; acc[TA][4 * q + 3] += v.w;
-    }
-  }
-}
-template <int T, int T0>
-__device__ __forceinline__ void add_chunk_from_lds(f32x16 (&acc)[T], const float* abuf, int i, int h) {
-  add_one_tile_from_lds<T, T0, 0>(acc, abuf, i, h);
-  add_one_tile_from_lds<T, T0 + 1, 1>(acc, abuf, i, h);
-}
-
-template <int T, int TA, int TT>
-__device__ __forceinline__ void one_tile_to_lds(const f32x16 (&o)[T], float* abuf, int i, int h) {
-  if constexpr (TA < T) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      f32x4 v = {o[TA][4 * q + 0], o[TA][4 * q + 1], o[TA][4 * q + 2], o[TA][4 * q + 3]};
-      *reinterpret_cast<f32x4*>(abuf + i * LDSW + 32 * TT + 8 * q + 4 * h) = v;
-    }
-  }
-}
-template <int T, int T0>
-__device__ __forceinline__ void chunk_to_lds(const f32x16 (&o)[T], float* abuf, int i, int h) {
-  one_tile_to_lds<T, T0, 0>(o, abuf, i, h);
-  one_tile_to_lds<T, T0 + 1, 1>(o, abuf, i, h);
-}
-
 // ADD2: additive segments are staged in pairs summed in registers (needs a second row set; off for the
 // 256-wide instance, which has no registers to spare).
 // DBUF: two weight buffers and one barrier per chunk; false (256-wide layers, whose 70 KB chunks do not

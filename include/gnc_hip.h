@@ -183,8 +183,9 @@ int gnc_mlp_forward_f32(const gnc_mlp_desc_t* desc /* host */, void* stream);
  *   The gradient of an ADD segment's table rows is dz[0] itself (scatter it by the segment's index);
  *   the gradient of the residual is grad_out.  Weight gradients: dW_l = dz[l]^T (input of Linear l),
  *   db_l = column sums of dz[l] -> gnc_xty_f32.
- *   Supported: ReLU, 2 <= num_linear <= 7, every width and every segment <= 64 columns, tables 16-B
- *   aligned with ld % 4 == 0, MATMUL segments listed before ADD segments (0 or 2 of them);
+ *   Supported: ReLU, 2 <= num_linear <= 7, tables 16-B aligned with ld % 4 == 0; widths <= 64 with every
+ *   segment <= 64 columns and MATMUL segments listed before 0 or 2 ADD segments run with LDS-resident
+ *   weights, other shapes up to width 128 stream the weights (also needs 16-B aligned weights);
  *   gnc_mlp_backward_supported() answers from the shape fields alone.
  *
  * gnc_xty_f32: partial[w] = [ A^T B (M x K, row-major) | column sums of A (M) ] over the rows wave w

@@ -323,6 +323,12 @@ def _torch_mlp(sd, x_cat, residual=None):
     ((64,), 64, 1, 2, False, False),       # decoder
     ((16, 16), 16, 16, 1, True, True),
     ((20,), 32, 8, 3, True, False),
+    ((128,), 128, 128, 2, True, False),       # widths 65..128: streamed-weights variant
+    ((128, 128), 128, 128, 2, True, True),
+    ((128, 128, 128), 128, 128, 2, True, True),
+    ((4,), 128, 128, 2, True, False),
+    ((128,), 128, 1, 2, False, False),
+    ((96, 40), 100, 72, 3, True, False),
 ])
 def test_mlp_backward_kernel_matches_autograd(native, in_dims, hidden, out_dim, hl, ln, res):
     """dz / act / dx / yhat of the K8 data kernel and the xty weight gradients against torch.autograd

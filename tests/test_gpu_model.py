@@ -222,19 +222,20 @@ def test_hip_backward_agrees_with_torch_recompute_backward(G, monkeypatch):
     from graphnet_classifier_amd import functional as Fn
     from graphnet_classifier_amd import synthetic as S
     batch = S.superpixel_like_graphs(6, seed=11)
-    torch.manual_seed(5)
-    m = G.GraphNet(**S.graphnet_kwargs(64, 2))
     x, pos, ei = batch.x.to(DEV), batch.pos.to(DEV), batch.edge_index.to(DEV)
     w = torch.randn(batch.num_nodes, 1, device=DEV)
-    grads = {}
-    for hip in (True, False):
-        monkeypatch.setattr(Fn, "HIP_BACKWARD", hip)
-        m.zero_grad()
-        (m(x, pos, ei) * w).sum().backward()
-        grads[hip] = {k: p.grad.clone() for k, p in m.named_parameters()}
-    for k in grads[True]:
-        a, b = grads[True][k], grads[False][k]
-        assert max_abs(a, b) < 1e-4 * max(1.0, float(b.abs().max())), k
+    for width in (64, 128):  # resident-weights and streamed-weights backward kernels
+        torch.manual_seed(5)
+        m = G.GraphNet(**S.graphnet_kwargs(width, 2))
+        grads = {}
+        for hip in (True, False):
+            monkeypatch.setattr(Fn, "HIP_BACKWARD", hip)
+            m.zero_grad()
+            (m(x, pos, ei) * w).sum().backward()
+            grads[hip] = {k: p.grad.clone() for k, p in m.named_parameters()}
+        for k in grads[True]:
+            a, b = grads[True][k], grads[False][k]
+            assert max_abs(a, b) < 1e-4 * max(1.0, float(b.abs().max())), (width, k)
 
 
 @pytest.mark.parametrize("case", ["no_edges", "one_node", "self_loops_and_duplicates", "isolated_tail"])
