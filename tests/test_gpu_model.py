@@ -293,6 +293,78 @@ def test_captured_forward_replays_bit_identically(G):
         assert torch.equal(cap(x).clone(), eager)
 
 
+@pytest.mark.parametrize("kw", [
+    dict(norm_type=None),
+    dict(activation="Tanh"),
+    dict(hidden_layers_node=1, hidden_layers_edge=3, hidden_layers_processor_node=3, hidden_layers_processor_edge=1,
+         hidden_layers_decoder=1),
+    dict(out_dim_node=48, out_dim_edge=24, hidden_dim_node=40, hidden_dim_edge=56, hidden_dim_processor_node=72,
+         hidden_dim_processor_edge=36, hidden_dim_decoder=20, out_channels=3),
+    dict(num_local_features=5, space_dim=3, num_global_features=2),
+    dict(initializer="xavier_uniform_"),
+])
+def test_graphnet_kwargs_variants_match_oracle(G, kw):
+    """Every constructor kwarg of models/GNN.py:230-254 that changes the arithmetic, against the oracle
+    (state dict exported from the module, so both sides use the same weights)."""
+    rng = np.random.default_rng(len(str(kw)))
+    n, e = 120, 700
+    nf = kw.get("num_local_features", 3) + kw.get("num_global_features", 0)
+    sdim = kw.get("space_dim", 2)
+    x = torch.from_numpy(rng.random((n, nf)).astype(np.float32))
+    pos = torch.from_numpy((rng.random((n, sdim)) * 16).astype(np.float32))
+    ei = torch.from_numpy(rng.integers(0, n, size=(2, e)).astype(np.int64))
+    base = dict(n_blocks=2, out_dim_node=32, out_dim_edge=32, hidden_dim_node=32, hidden_dim_edge=32,
+                hidden_dim_decoder=32, hidden_dim_processor_node=32, hidden_dim_processor_edge=32)
+    base.update(kw)
+    torch.manual_seed(3)
+    m = G.GraphNet(**base)
+    with torch.no_grad():
+        y = m(x, pos, ei)
+    if kw.get("activation") == "Tanh":
+        # the oracle restates ReLU only (the reference never uses another activation); check against torch modules
+        ref_mod = {k: v.cpu() for k, v in m.state_dict().items()}
+        import torch.nn.functional as F
+
+        def mlp(prefix, t, ln=True):
+            idx = sorted({int(k[len(prefix) + 7:].split(".")[0]) for k in ref_mod if k.startswith(prefix + ".model.")})
+            lin = [i for i in idx if ref_mod[f"{prefix}.model.{i}.weight"].ndim == 2]
+            for q, i in enumerate(lin):
+                t = F.linear(t, ref_mod[f"{prefix}.model.{i}.weight"], ref_mod[f"{prefix}.model.{i}.bias"])
+                if q + 1 < len(lin):
+                    t = torch.tanh(t) if "decoder" not in prefix else torch.relu(t)  # decoder keeps the default ReLU (:289-295)
+            nrm = [i for i in idx if ref_mod[f"{prefix}.model.{i}.weight"].ndim == 1]
+            for i in nrm:
+                t = F.layer_norm(t, (t.size(-1),), ref_mod[f"{prefix}.model.{i}.weight"], ref_mod[f"{prefix}.model.{i}.bias"])
+            return t
+        ef = O.edge_features(pos, ei)
+        hh, ee = mlp("node_encoder", x), mlp("edge_encoder", ef)
+        for b in range(2):
+            p = f"graph_processor.blocks.{b}"
+            ee = mlp(p + ".edge_model.edge_processor", torch.cat([hh[ei[0]], hh[ei[1]], ee], -1)) + ee
+            agg = O.scatter_sum_fast(ee, ei[1], n)
+            hh = mlp(p + ".node_model.node_processor", torch.cat([hh, agg], -1)) + hh
+        ref = mlp("node_decoder", hh)
+    else:
+        ref = O.graphnet_forward({k: v.cpu() for k, v in m.state_dict().items()}, x, pos, ei)
+    assert y.shape == ref.shape and max_abs(y, ref) < 2e-5
+
+
+def test_batchnorm_norm_type_runs_through_the_kernel_plus_a_rocm_op(G):
+    """norm_type='BatchNorm1d' is legal in models/MLP.py:30-35 (never used by the reference's entry points)."""
+    from graphnet_classifier_amd.MLP import MLP
+    torch.manual_seed(0)
+    m = MLP(12, 20, hidden_dim=32, hidden_layers=2, norm_type="BatchNorm1d")
+    x = torch.randn(50, 12)
+    ref = torch.nn.Sequential(*[type(l)(**({"in_features": l.in_features, "out_features": l.out_features} if isinstance(l, torch.nn.Linear)
+                                             else {"num_features": l.num_features} if isinstance(l, torch.nn.BatchNorm1d) else {}))
+                                for l in m.model])
+    ref.load_state_dict({k: v.cpu() for k, v in m.model.state_dict().items()})
+    for mode in ("train", "eval"):
+        getattr(m, mode)(); getattr(ref, mode)()
+        with torch.no_grad():
+            assert max_abs(m(x), ref(x)) < 2e-5
+
+
 def test_forward_on_cpu_module_fails_loudly(G):
     m = G.GraphNet(**{"n_blocks": 1}).to("cpu")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
