@@ -41,25 +41,31 @@ class MLP(nn.Module):
         initializer: None | str = None,
         norm_type: None | str = "LayerNorm",
     ):
-        """Linear/act x hidden_layers, Linear, optional norm (models/MLP.py:24-37)."""
+        """Linear/act x hidden_layers, Linear, optional norm (models/MLP.py:24-37).
+
+        The Sequential built here has exactly the reference's module order (Linear at even positions,
+        the shared activation module between them, the norm last) so ``state_dict`` keys and the random
+        initialisation under a given seed are the same."""
         super().__init__()
-        self.activation = getattr(nn, activation)()
         self.activation_name = activation
-        if initializer is not None:
-            self.initializer = getattr(nn.init, initializer)
-        layers = [nn.Linear(in_dim, hidden_dim), self.activation]
-        for _ in range(hidden_layers - 1):
-            layers += [nn.Linear(hidden_dim, hidden_dim), self.activation]
-        layers.append(nn.Linear(hidden_dim, out_dim))
+        self.activation = getattr(nn, activation)()  # AttributeError for an unknown name, as in the reference
         if norm_type is not None:
             assert norm_type in ["LayerNorm", "BatchNorm1d"]  # models/MLP.py:30-33
-            layers.append(getattr(nn, norm_type)(out_dim))
         self.norm_type = norm_type
-        self.model = nn.Sequential(*layers)
+        widths = [in_dim] + [hidden_dim] * max(int(hidden_layers), 1) + [out_dim]
+        chain = []
+        for k in range(len(widths) - 1):
+            chain.append(nn.Linear(widths[k], widths[k + 1]))
+            if k + 2 < len(widths):
+                chain.append(self.activation)
+        if norm_type is not None:
+            chain.append(getattr(nn, norm_type)(out_dim))
+        self.model = nn.Sequential(*chain)
         if initializer is not None:
-            for param in self.model.parameters():
-                if param.requires_grad and len(param.shape) > 1:
-                    self.initializer(param)
+            self.initializer = getattr(nn.init, initializer)
+            for tensor in self.model.parameters():
+                if tensor.requires_grad and tensor.dim() > 1:
+                    self.initializer(tensor)
         self.to(default_device())
 
     # -- pieces of the Sequential the kernel consumes ------------------------------------
