@@ -259,6 +259,10 @@ extern "C" int gnc_mlp_forward_f32(const gnc_mlp_desc_t* desc, void* stream_) {
   bool launched = false;  // weights-resident variant first (decides by LDS fit)
   rc = launch_resident(*desc, T, narrow_out, stream, &launched);
   if (rc || launched) return rc;
+  if (T == 8) {  // 129..256 features: 16-row tiles on the 16x16x4 MFMA
+    rc = launch_stream16(*desc, stream, &launched);
+    if (rc || launched) return rc;
+  }
   rc = launch_stream(*desc, T, narrow_out, stream, &launched);  // wide layers: double-buffered weight stream
   if (rc || launched) return rc;
 

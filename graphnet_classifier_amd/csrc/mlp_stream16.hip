@@ -1,0 +1,443 @@
+// K4, streaming FAST variant for hidden widths 129..256, built on v_mfma_f32_16x16x4_f32.
+//
+// At 256 features the 32-row formulation needs 2 x 128 accumulator registers per wave (the current and
+// the next layer), which forces one wave per SIMD and still spills (47 % of the fp32 MFMA peak at config
+// c5).  With the 16x16x4 shape a wave owns 16 data rows: the same 256 features are 16 tiles x 4
+// registers = 64 registers, two layers fit in 128, and the kernel runs 8 waves per CU (2 per SIMD) without
+// spilling.  The formulation is the same as mlp_fused.hip, transposed: accumulator register r of tile t on
+// lane (j = lane & 15, g = lane >> 4) holds feature 16t + 4g + r of data row j, which is exactly the B
+// operand (k = 4g + r within the 16-wide k block t) of the next Linear; the matching A operand is
+// W[n][16t + 4g .. +3], one ds_read_b128.  Weight chunks ([features][64 k], padded rows of 68 floats) are
+// prefetched into registers under the MFMAs of the previous chunk and written between two barriers (one
+// 70 KB buffer: two do not fit next to the row tiles); rows are staged 16 per wave.
+#include <stdlib.h>
+
+#include "mlp_device.h"
+
+using namespace gnc_mlp;
+
+namespace {
+
+constexpr int R16 = 16;         // data rows per wave
+constexpr int NP16 = R16 / 4;   // staging passes (4 rows per wave instruction)
+constexpr int W16 = 8;          // waves per workgroup
+constexpr int NT16 = W16 * 64;
+constexpr int MAX_STEPS16 = 16;
+constexpr int MAX_WCHUNKS16 = 40;
+
+struct Plan16 {
+  int num_steps;
+  int num_wchunks;
+  struct { short seg, c0, add, pad; } step[MAX_STEPS16];
+  struct { short layer, kbase, klimit, pad; } wc[MAX_WCHUNKS16];
+};
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// NTL = number of 16-feature tiles (16 for 256 features)
+template <int NTL>
+__device__ __forceinline__ void init_bias16(f32x4 (&acc)[NTL], const float* pb, int g) {
+#pragma unroll
+  for (int t = 0; t < NTL; ++t) acc[t] = *reinterpret_cast<const f32x4*>(pb + 16 * t + 4 * g);
+}
+
+template <int NTL>
+__device__ __forceinline__ void relu16(f32x4 (&acc)[NTL]) {
+#pragma unroll
+  for (int t = 0; t < NTL; ++t) {
+    acc[t].x = fmaxf(acc[t].x, 0.f); acc[t].y = fmaxf(acc[t].y, 0.f);
+    acc[t].z = fmaxf(acc[t].z, 0.f); acc[t].w = fmaxf(acc[t].w, 0.f);
+  }
+}
+
+// acc[t] += W_chunk[16t + i][16cb + 4g + s] * X[j][16cb + 4g + s]: one staged 64-column chunk of the first Linear
+template <int NTL>
+__device__ __forceinline__ void mma16_chunk_from_lds(f32x4 (&acc)[NTL], const float* abuf, const float* wbuf, int kc16,
+                                                     int i, int g) {
+  for (int cb = 0; cb < kc16; ++cb) {
+    const f32x4 b = *reinterpret_cast<const f32x4*>(abuf + i * LDSW + 16 * cb + 4 * g);
+    const float bs[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int th = 0; th < NTL; th += 4) {  // four tiles at a time: independent accumulators between dependent steps
+      f32x4 a[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const f32x4*>(wbuf + (16 * (th + u) + i) * LDSW + 16 * cb + 4 * g);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float av = s == 0 ? a[u].x : s == 1 ? a[u].y : s == 2 ? a[u].z : a[u].w;
+          acc[th + u] = mfma16(av, bs[s], acc[th + u]);
+        }
+      __builtin_amdgcn_sched_barrier(0);  // one group of A fragments in flight at a time (register budget)
+    }
+  }
+}
+
+// dst[t] += W_chunk * src for the 64-column chunk c of a Linear fed by the previous layer's accumulators
+template <int NTI, int NTO, int C>
+__device__ __forceinline__ void mma16_chunk_from_regs(f32x4 (&dst)[NTO], const f32x4 (&src)[NTI], const float* wbuf,
+                                                      int in_dim, int i, int g) {
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb) {
+    const int ts = 4 * C + cb;
+    if (ts < NTI && 16 * ts < in_dim) {
+      const f32x4 sv = src[ts < NTI ? ts : 0];
+      const float bs[4] = {sv.x, sv.y, sv.z, sv.w};
+#pragma unroll
+      for (int th = 0; th < NTO; th += 4) {
+        f32x4 a[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          a[u] = *reinterpret_cast<const f32x4*>(wbuf + (16 * (th + u < NTO ? th + u : 0) + i) * LDSW + 16 * cb + 4 * g);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (th + u < NTO) {
+              const float av = s == 0 ? a[u].x : s == 1 ? a[u].y : s == 2 ? a[u].z : a[u].w;
+              dst[th + u] = mfma16(av, bs[s], dst[th + u]);
+            }
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+}
+
+template <int NTL>
+__device__ __forceinline__ void layer_norm16(f32x4 (&o)[NTL], const float* pg, const float* pbt, int out_dim, float eps,
+                                             int g) {
+  float s = 0.f;
+#pragma unroll
+  for (int t = 0; t < NTL; ++t) {
+    const int f = 16 * t + 4 * g;
+    s += (f + 0 < out_dim ? o[t].x : 0.f) + (f + 1 < out_dim ? o[t].y : 0.f) + (f + 2 < out_dim ? o[t].z : 0.f) +
+         (f + 3 < out_dim ? o[t].w : 0.f);
+  }
+  s += __shfl_xor(s, 16, 64);
+  s += __shfl_xor(s, 32, 64);
+  const float mean = s / (float)out_dim;
+  float v = 0.f;
+#pragma unroll
+  for (int t = 0; t < NTL; ++t) {
+    const int f = 16 * t + 4 * g;
+    const float d0 = o[t].x - mean, d1 = o[t].y - mean, d2 = o[t].z - mean, d3 = o[t].w - mean;
+    v += (f + 0 < out_dim ? d0 * d0 : 0.f) + (f + 1 < out_dim ? d1 * d1 : 0.f) + (f + 2 < out_dim ? d2 * d2 : 0.f) +
+         (f + 3 < out_dim ? d3 * d3 : 0.f);
+  }
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  const float rstd = 1.f / sqrtf(v / (float)out_dim + eps);
+#pragma unroll
+  for (int t = 0; t < NTL; ++t) {
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(pg + 16 * t + 4 * g);
+    const f32x4 bt = *reinterpret_cast<const f32x4*>(pbt + 16 * t + 4 * g);
+    o[t].x = (o[t].x - mean) * rstd * gm.x + bt.x; o[t].y = (o[t].y - mean) * rstd * gm.y + bt.y;
+    o[t].z = (o[t].z - mean) * rstd * gm.z + bt.z; o[t].w = (o[t].w - mean) * rstd * gm.w + bt.w;
+  }
+}
+
+// NTH / NTO: 16-feature tiles of the hidden / output width (4, 8 or 16; NTO may be 1 for the decoder)
+template <int NTH, int NTO>
+__global__ __launch_bounds__(NT16) void mlp_stream16_kernel(const gnc_mlp_desc_t d, const Plan16 pl, const int num_tiles) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int NTW = NTH > NTO ? NTH : NTO;
+  constexpr int WROWS = NTW * 16;             // weight rows per chunk buffer
+  constexpr int CH = WROWS * LDSW;
+  constexpr int PSTRIDE = WROWS;
+  constexpr int RPP = NT16 / 16;              // weight rows staged per pass (32)
+  constexpr int NW = WROWS / RPP;
+  constexpr int NCHI = (NTH + 3) / 4;         // 64-column chunks of a hidden-width input
+  constexpr int NCHO = (NTO + 3) / 4;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15;   // feature row of the A operand == data row of the B operand / accumulator column
+  const int g = lane >> 4;
+  const int c4 = lane & 15;  // staging role
+  const int rs = lane >> 4;
+  const int wc4 = tid & 15;
+  const int wr0 = tid >> 4;
+  const int L = d.num_linear;
+  const int out_dim = d.out_dim[L - 1];
+  const int rows = (int)d.rows;
+  float* wbuf = lds;  // ONE chunk buffer: two 70 KB buffers do not fit next to the row tiles
+  float* pbuf = lds + CH;
+  float* abuf = pbuf + (L + 2) * PSTRIDE + wave * R16 * LDSW;
+
+  stage_params<NT16>(pbuf, d, PSTRIDE, tid);
+
+  auto wload = [&](f32x4 (&wr)[NW], int q) {
+    const int layer = pl.wc[q].layer;
+    const float* W = d.weight[layer];
+    const int ldw = ldw_of(d, layer);
+    const int nrows = d.out_dim[layer];
+    const int klimit = pl.wc[q].klimit;
+    const int col = pl.wc[q].kbase + wc4 * 4;
+    const int colc = col < klimit ? col : pl.wc[q].kbase;
+#pragma unroll
+    for (int p = 0; p < NW; ++p) {
+      const int n = p * RPP + wr0;
+      const int nc = n < nrows ? n : nrows - 1;
+      f32x4 v = *reinterpret_cast<const f32x4*>(W + (int64_t)nc * ldw + colc);
+      const bool rowok = n < nrows;
+      v.x = (rowok && col + 0 < klimit) ? v.x : 0.f; v.y = (rowok && col + 1 < klimit) ? v.y : 0.f;
+      v.z = (rowok && col + 2 < klimit) ? v.z : 0.f; v.w = (rowok && col + 3 < klimit) ? v.w : 0.f;
+      wr[p] = v;
+    }
+  };
+  auto wstore = [&](const f32x4 (&wr)[NW], float* buf) {
+#pragma unroll
+    for (int p = 0; p < NW; ++p) *reinterpret_cast<f32x4*>(buf + (p * RPP + wr0) * LDSW + wc4 * 4) = wr[p];
+  };
+  const int last_tile = num_tiles - 1;
+  auto load_idx = [&](int tile, int s) -> int {
+    const int tc = tile < last_tile ? tile : last_tile;
+    int r = (tc * W16 + wave) * R16 + (lane & 15);
+    r = r < rows ? r : rows - 1;
+    const int32_t* ip = d.seg[s].index;
+    return ip ? ip[r] : r;
+  };
+  auto load_rows = [&](f32x4 (&pre)[NP16], int s, int c0, int idxv) {
+    const float* base = d.seg[s].ptr;
+    const int ld = d.seg[s].ld;
+    const int col = c0 + c4 * 4 < ld ? c0 + c4 * 4 : 0;
+#pragma unroll
+    for (int p = 0; p < NP16; ++p) {
+      const int tr = __shfl(idxv, p * 4 + rs, 64);
+      pre[p] = *reinterpret_cast<const f32x4*>(base + (int64_t)tr * ld + col);
+    }
+  };
+  auto stage = [&](const f32x4 (&pre)[NP16], int c0, int width) {
+    compiler_lds_barrier();
+    const int c = c0 + c4 * 4;
+#pragma unroll
+    for (int p = 0; p < NP16; ++p) {
+      f32x4 v = pre[p];
+      v.x = c + 0 < width ? v.x : 0.f; v.y = c + 1 < width ? v.y : 0.f;
+      v.z = c + 2 < width ? v.z : 0.f; v.w = c + 3 < width ? v.w : 0.f;
+      *reinterpret_cast<f32x4*>(abuf + (p * 4 + rs) * LDSW + c4 * 4) = v;
+    }
+    compiler_lds_barrier();
+  };
+
+  int ids[GNC_MAX_SEGMENTS], ids_next[GNC_MAX_SEGMENTS];
+  int tile = blockIdx.x;
+#pragma unroll
+  for (int s = 0; s < GNC_MAX_SEGMENTS; ++s) {
+    ids[s] = s < d.num_segments ? load_idx(tile, s) : 0;
+    ids_next[s] = s < d.num_segments ? load_idx(tile + (int)gridDim.x, s) : 0;
+  }
+  auto id_of = [&](int s) {
+    int v = 0;
+#pragma unroll
+    for (int k = 0; k < GNC_MAX_SEGMENTS; ++k) v = k == s ? ids[k] : v;
+    return v;
+  };
+  f32x4 cur[NP16];
+  load_rows(cur, pl.step[0].seg, pl.step[0].c0, id_of(pl.step[0].seg));
+  f32x4 wreg[NW];
+  wload(wreg, 0);
+  wstore(wreg, wbuf);
+  __syncthreads();
+  auto prefetch_next_chunk = [&](int q) { wload(wreg, q + 1 < pl.num_wchunks ? q + 1 : 0); };
+  auto publish_next_chunk = [&]() {
+    __syncthreads();  // everyone is done reading the buffer
+    wstore(wreg, wbuf);
+    __syncthreads();
+  };
+
+  while (tile < num_tiles) {
+    const int row0 = (tile * W16 + wave) * R16;
+    const int ntile = tile + gridDim.x;
+    int q = 0;
+
+    // ------------------------------------------------------------------ first Linear
+    f32x4 hid[NTH];
+    init_bias16<NTH>(hid, pbuf, g);
+    for (int st = 0; st < pl.num_steps; ++st) {
+      const int s = pl.step[st].seg, c0 = pl.step[st].c0;
+      const int width = d.seg[s].width;
+      stage(cur, c0, width);
+      {
+        const bool wrap = st + 1 >= pl.num_steps;
+        const int nst = wrap ? 0 : st + 1;
+        if (wrap) {
+#pragma unroll
+          for (int k = 0; k < GNC_MAX_SEGMENTS; ++k) {
+            ids[k] = ids_next[k];
+            if (k < d.num_segments) ids_next[k] = load_idx(ntile + (int)gridDim.x, k);
+          }
+        }
+        load_rows(cur, pl.step[nst].seg, pl.step[nst].c0, id_of(pl.step[nst].seg));
+      }
+      if (pl.step[st].add) {  // rows already in the hidden width: acc[t] += staged columns (tile t = c0/16 + cb)
+        const int t0 = c0 >> 4;
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(abuf + i * LDSW + 16 * cb + 4 * g);
+#pragma unroll
+          for (int t = 0; t < NTH; ++t)
+            if (t == t0 + cb) hid[t] += v;  // wave-uniform select; unrolled so the register index stays static
+        }
+      } else {
+        prefetch_next_chunk(q);
+        const int kc = width - c0 < KC ? width - c0 : KC;
+        mma16_chunk_from_lds<NTH>(hid, abuf, wbuf, (kc + 15) >> 4, i, g);
+        publish_next_chunk();
+        ++q;
+      }
+    }
+
+    f32x4 o[NTO];
+    if (L == 1) {
+      if (d.ln_gamma) layer_norm16<NTH>(hid, pbuf + L * PSTRIDE, pbuf + (L + 1) * PSTRIDE, out_dim, d.ln_eps, g);
+      if constexpr (NTO == NTH) {
+#pragma unroll
+        for (int t = 0; t < NTO; ++t) o[t] = hid[t];
+      }
+    } else {
+      relu16<NTH>(hid);
+      for (int l = 1; l < L - 1; ++l) {
+        f32x4 nxt[NTH];
+        init_bias16<NTH>(nxt, pbuf + l * PSTRIDE, g);
+#define GNC_HID_CHUNK(C_)                                                                        \
+  if constexpr (C_ < NCHI) {                                                                     \
+    if (C_ * KC < d.in_dim[l]) {                                                                 \
+      prefetch_next_chunk(q);                                                                    \
+      mma16_chunk_from_regs<NTH, NTH, C_>(nxt, hid, wbuf, d.in_dim[l], i, g);   \
+      publish_next_chunk();                                                                      \
+      ++q;                                                                                       \
+    }                                                                                            \
+  }
+        GNC_HID_CHUNK(0) GNC_HID_CHUNK(1) GNC_HID_CHUNK(2) GNC_HID_CHUNK(3)
+#undef GNC_HID_CHUNK
+        relu16<NTH>(nxt);
+#pragma unroll
+        for (int t = 0; t < NTH; ++t) hid[t] = nxt[t];
+      }
+      init_bias16<NTO>(o, pbuf + (L - 1) * PSTRIDE, g);
+#define GNC_OUT_CHUNK(C_)                                                                          \
+  if constexpr (C_ < NCHI) {                                                                       \
+    if (C_ * KC < d.in_dim[L - 1]) {                                                               \
+      prefetch_next_chunk(q);                                                                      \
+      mma16_chunk_from_regs<NTH, NTO, C_>(o, hid, wbuf, d.in_dim[L - 1], i, g);   \
+      publish_next_chunk();                                                                        \
+      ++q;                                                                                         \
+    }                                                                                              \
+  }
+      GNC_OUT_CHUNK(0) GNC_OUT_CHUNK(1) GNC_OUT_CHUNK(2) GNC_OUT_CHUNK(3)
+#undef GNC_OUT_CHUNK
+      if (d.ln_gamma) layer_norm16<NTO>(o, pbuf + L * PSTRIDE, pbuf + (L + 1) * PSTRIDE, out_dim, d.ln_eps, g);
+    }
+
+    // collect the next tile's prefetched rows before the asm stores join the memory queue
+#pragma unroll
+    for (int p = 0; p < NP16; ++p) asm volatile("" ::"v"(cur[p]));
+
+    // ------------------------------------------------------------------ epilogue: 64 output columns at a time
+    const bool vec_out = (out_dim % 4 == 0) && (d.ld_out % 4 == 0) && ((reinterpret_cast<uintptr_t>(d.out) & 15u) == 0);
+#pragma unroll
+    for (int cc = 0; cc < NCHO; ++cc) {
+      if (cc * KC < out_dim) {
+        compiler_lds_barrier();
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+          if (4 * cc + cb < NTO) *reinterpret_cast<f32x4*>(abuf + i * LDSW + 16 * cb + 4 * g) = o[4 * cc + cb < NTO ? 4 * cc + cb : 0];
+        compiler_lds_barrier();
+        const int col = cc * KC + c4 * 4;
+        const bool col_ok = col < out_dim;
+        const int colc = col_ok ? col : 0;
+        f32x4 outv[NP16];
+#pragma unroll
+        for (int p = 0; p < NP16; ++p) outv[p] = *reinterpret_cast<const f32x4*>(abuf + (p * 4 + rs) * LDSW + c4 * 4);
+        if (d.residual) {
+          const int rc = colc < d.ld_residual ? colc : 0;
+#pragma unroll
+          for (int p = 0; p < NP16; ++p) {
+            int r = row0 + p * 4 + rs;
+            r = r < rows ? r : rows - 1;
+            outv[p] += *reinterpret_cast<const f32x4*>(d.residual + (int64_t)r * d.ld_residual + rc);
+          }
+        }
+#pragma unroll
+        for (int p = 0; p < NP16; ++p) {
+          const int r = row0 + p * 4 + rs;
+          store_row_piece(d.out + (int64_t)(r < rows ? r : rows - 1) * d.ld_out, col, outv[p], r < rows && col_ok, out_dim,
+                          vec_out);
+        }
+      }
+    }
+    compiler_lds_barrier();
+    tile = ntile;
+  }
+}
+
+template <int NTH, int NTO>
+int launch16(const gnc_mlp_desc_t& d, const Plan16& pl, hipStream_t stream) {
+  constexpr int NTW = NTH > NTO ? NTH : NTO;
+  const size_t smem =
+      ((size_t)NTW * 16 * LDSW + (size_t)(d.num_linear + 2) * NTW * 16 + (size_t)W16 * R16 * LDSW) * sizeof(float);
+  if (smem > 160 * 1024) {
+    gnc::set_error("mlp_stream16: LDS budget exceeded (%zu bytes)", smem);
+    return GNC_ERR_UNSUPPORTED;
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    int rc = gnc::check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_stream16_kernel<NTH, NTO>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                            "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    if (rc) return rc;
+    attr_set = true;
+  }
+  const int64_t num_tiles = gnc::ceil_div(d.rows, (int64_t)W16 * R16);
+  const int64_t grid = num_tiles < gnc::kNumCU ? num_tiles : gnc::kNumCU;
+  mlp_stream16_kernel<NTH, NTO><<<dim3((unsigned)grid), dim3(NT16), smem, stream>>>(d, pl, (int)num_tiles);
+  return gnc::check_launch("mlp_stream16_kernel");
+}
+
+bool al16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+
+int gnc_mlp::launch_stream16(const gnc_mlp_desc_t& d, hipStream_t stream, bool* launched) {
+  *launched = false;
+  static const bool disabled = getenv("GNC_MLP_NO_STREAM16") != nullptr;  // A/B switch for benchmarking
+  if (disabled || d.rows >= INT32_MAX) return GNC_OK;
+  const int L = d.num_linear;
+  if (L > 1 && d.activation != GNC_ACT_RELU) return GNC_OK;
+  const int H = d.out_dim[0], od = d.out_dim[L - 1];
+  if (H > 256 || od > 256) return GNC_OK;
+  if (d.residual && (d.ld_residual % 4 != 0 || !al16p(d.residual))) return GNC_OK;
+  for (int l = 0; l < L; ++l)
+    if (ldw_of(d, l) % 4 != 0 || !al16p(d.weight[l])) return GNC_OK;
+  Plan16 pl = {};
+  for (int pass = 0; pass < 2; ++pass)  // MATMUL segments first, then the additive ones
+    for (int s = 0; s < d.num_segments; ++s) {
+      const gnc_mlp_segment_t& sg = d.seg[s];
+      if (sg.ld % 4 != 0 || !al16p(sg.ptr)) return GNC_OK;
+      const bool add = sg.mode == GNC_SEG_ADD;
+      if ((pass == 1) != add) continue;
+      if (!add && sg.wcol % 4 != 0) return GNC_OK;
+      for (int c0 = 0; c0 < sg.width; c0 += KC) {
+        if (pl.num_steps >= MAX_STEPS16) return GNC_OK;
+        pl.step[pl.num_steps++] = {(short)s, (short)c0, (short)(add ? 1 : 0), 0};
+        if (!add) {
+          if (pl.num_wchunks >= MAX_WCHUNKS16) return GNC_OK;
+          pl.wc[pl.num_wchunks++] = {(short)0, (short)(sg.wcol + c0), (short)(sg.wcol + sg.width), 0};
+        }
+      }
+    }
+  if (pl.num_wchunks == 0) return GNC_OK;
+  for (int l = 1; l < L; ++l)
+    for (int c = 0; c * KC < d.in_dim[l]; ++c) {
+      if (pl.num_wchunks >= MAX_WCHUNKS16) return GNC_OK;
+      pl.wc[pl.num_wchunks++] = {(short)l, (short)(c * KC), (short)d.in_dim[l], 0};
+    }
+  *launched = true;
+  if (od <= 16 && L > 1) return launch16<16, 1>(d, pl, stream);
+  return launch16<16, 16>(d, pl, stream);
+}
