@@ -20,6 +20,8 @@
 // segment has one) are staged per wave into a private [32][64] LDS tile with whole-row 16-B
 // loads.  LDS rows are padded to 68 floats (4*odd) which makes every ds_read_b128 fragment
 // read conflict-free.  mlp_resident.hip holds the variant for widths whose weights fit in LDS.
+#include <stdlib.h>
+
 #include "mlp_device.h"
 
 using namespace gnc_mlp;
@@ -259,7 +261,8 @@ extern "C" int gnc_mlp_forward_f32(const gnc_mlp_desc_t* desc, void* stream_) {
   bool launched = false;  // weights-resident variant first (decides by LDS fit)
   rc = launch_resident(*desc, T, narrow_out, stream, &launched);
   if (rc || launched) return rc;
-  if (T == 8) {  // 129..256 features: 16-row tiles on the 16x16x4 MFMA
+  static const bool s16_128 = getenv("GNC_STREAM16_D128") != nullptr;  // A/B: 16-row kernel also for 65..128 features
+  if (T == 8 || (T == 4 && s16_128)) {  // 129..256 features: 16-row tiles on the 16x16x4 MFMA
     rc = launch_stream16(*desc, stream, &launched);
     if (rc || launched) return rc;
   }

@@ -141,7 +141,7 @@ __device__ __forceinline__ void layer_norm16(f32x4 (&o)[NTL], const float* pg, c
 }
 
 // NTH / NTO: 16-feature tiles of the hidden / output width (4, 8 or 16; NTO may be 1 for the decoder)
-template <int NTH, int NTO>
+template <int NTH, int NTO, bool DBUF>
 __global__ __launch_bounds__(NT16) void mlp_stream16_kernel(const gnc_mlp_desc_t d, const Plan16 pl, const int num_tiles) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int NTW = NTH > NTO ? NTH : NTO;
@@ -164,8 +164,9 @@ __global__ __launch_bounds__(NT16) void mlp_stream16_kernel(const gnc_mlp_desc_t
   const int L = d.num_linear;
   const int out_dim = d.out_dim[L - 1];
   const int rows = (int)d.rows;
-  float* wbuf = lds;  // ONE chunk buffer: two 70 KB buffers do not fit next to the row tiles
-  float* pbuf = lds + CH;
+  float* wbuf = lds;  // DBUF: two chunk buffers (<= 128 features); at 256 features only one 70 KB buffer fits
+  float* pbuf = lds + (DBUF ? 2 : 1) * CH;
+  int gq = 0;
   float* abuf = pbuf + (L + 2) * PSTRIDE + wave * R16 * LDSW;
 
   stage_params<NT16>(pbuf, d, PSTRIDE, tid);
@@ -245,10 +246,17 @@ __global__ __launch_bounds__(NT16) void mlp_stream16_kernel(const gnc_mlp_desc_t
   __syncthreads();
   auto prefetch_next_chunk = [&](int q) { wload(wreg, q + 1 < pl.num_wchunks ? q + 1 : 0); };
   auto publish_next_chunk = [&]() {
-    __syncthreads();  // everyone is done reading the buffer
-    wstore(wreg, wbuf);
-    __syncthreads();
+    if constexpr (DBUF) {
+      wstore(wreg, wbuf + ((gq + 1) & 1) * CH);
+      __syncthreads();
+      ++gq;
+    } else {
+      __syncthreads();  // everyone is done reading the buffer
+      wstore(wreg, wbuf);
+      __syncthreads();
+    }
   };
+  auto cur_w = [&]() -> const float* { return wbuf + (DBUF ? (gq & 1) : 0) * CH; };
 
   while (tile < num_tiles) {
     const int row0 = (tile * W16 + wave) * R16;
@@ -286,7 +294,7 @@ __global__ __launch_bounds__(NT16) void mlp_stream16_kernel(const gnc_mlp_desc_t
       } else {
         prefetch_next_chunk(q);
         const int kc = width - c0 < KC ? width - c0 : KC;
-        mma16_chunk_from_lds<NTH>(hid, abuf, wbuf, (kc + 15) >> 4, i, g);
+        mma16_chunk_from_lds<NTH>(hid, abuf, cur_w(), (kc + 15) >> 4, i, g);
         publish_next_chunk();
         ++q;
       }
@@ -308,7 +316,7 @@ __global__ __launch_bounds__(NT16) void mlp_stream16_kernel(const gnc_mlp_desc_t
   if constexpr (C_ < NCHI) {                                                                     \
     if (C_ * KC < d.in_dim[l]) {                                                                 \
       prefetch_next_chunk(q);                                                                    \
-      mma16_chunk_from_regs<NTH, NTH, C_>(nxt, hid, wbuf, d.in_dim[l], i, g);   \
+      mma16_chunk_from_regs<NTH, NTH, C_>(nxt, hid, cur_w(), d.in_dim[l], i, g);   \
       publish_next_chunk();                                                                      \
       ++q;                                                                                       \
     }                                                                                            \
@@ -324,7 +332,7 @@ __global__ __launch_bounds__(NT16) void mlp_stream16_kernel(const gnc_mlp_desc_t
   if constexpr (C_ < NCHI) {                                                                       \
     if (C_ * KC < d.in_dim[L - 1]) {                                                               \
       prefetch_next_chunk(q);                                                                      \
-      mma16_chunk_from_regs<NTH, NTO, C_>(o, hid, wbuf, d.in_dim[L - 1], i, g);   \
+      mma16_chunk_from_regs<NTH, NTO, C_>(o, hid, cur_w(), d.in_dim[L - 1], i, g);   \
       publish_next_chunk();                                                                        \
       ++q;                                                                                         \
     }                                                                                              \
@@ -379,15 +387,16 @@ __global__ __launch_bounds__(NT16) void mlp_stream16_kernel(const gnc_mlp_desc_t
 template <int NTH, int NTO>
 int launch16(const gnc_mlp_desc_t& d, const Plan16& pl, hipStream_t stream) {
   constexpr int NTW = NTH > NTO ? NTH : NTO;
+  constexpr bool DBUF = NTW <= 8;
   const size_t smem =
-      ((size_t)NTW * 16 * LDSW + (size_t)(d.num_linear + 2) * NTW * 16 + (size_t)W16 * R16 * LDSW) * sizeof(float);
+      ((size_t)(DBUF ? 2 : 1) * NTW * 16 * LDSW + (size_t)(d.num_linear + 2) * NTW * 16 + (size_t)W16 * R16 * LDSW) * sizeof(float);
   if (smem > 160 * 1024) {
     gnc::set_error("mlp_stream16: LDS budget exceeded (%zu bytes)", smem);
     return GNC_ERR_UNSUPPORTED;
   }
   static bool attr_set = false;
   if (!attr_set) {
-    int rc = gnc::check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_stream16_kernel<NTH, NTO>),
+    int rc = gnc::check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_stream16_kernel<NTH, NTO, DBUF>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
                             "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc) return rc;
@@ -395,7 +404,7 @@ int launch16(const gnc_mlp_desc_t& d, const Plan16& pl, hipStream_t stream) {
   }
   const int64_t num_tiles = gnc::ceil_div(d.rows, (int64_t)W16 * R16);
   const int64_t grid = num_tiles < gnc::kNumCU ? num_tiles : gnc::kNumCU;
-  mlp_stream16_kernel<NTH, NTO><<<dim3((unsigned)grid), dim3(NT16), smem, stream>>>(d, pl, (int)num_tiles);
+  mlp_stream16_kernel<NTH, NTO, DBUF><<<dim3((unsigned)grid), dim3(NT16), smem, stream>>>(d, pl, (int)num_tiles);
   return gnc::check_launch("mlp_stream16_kernel");
 }
 
@@ -438,6 +447,10 @@ int gnc_mlp::launch_stream16(const gnc_mlp_desc_t& d, hipStream_t stream, bool* 
       pl.wc[pl.num_wchunks++] = {(short)l, (short)(c * KC), (short)d.in_dim[l], 0};
     }
   *launched = true;
+  if (H <= 128 && od <= 128) {
+    if (od <= 16 && L > 1) return launch16<8, 1>(d, pl, stream);
+    return launch16<8, 8>(d, pl, stream);
+  }
   if (od <= 16 && L > 1) return launch16<16, 1>(d, pl, stream);
   return launch16<16, 16>(d, pl, stream);
 }
