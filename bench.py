@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(synthetic.WORKLOADS))
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scale", type=float, default=1.0,
+                    help="fraction of the workload's graphs (tests / rehearsals only; the contract number is --scale 1)")
     ap.add_argument("--mode", default="forward", choices=["forward", "train"],
                     help="train: forward + cross-entropy + backward (HIP K8 kernels) + one flat gradient all-reduce "
                          "(RCCL, world > 1) + Adam, graphs batched block-diagonally (c3/c5 only: equal-size graphs)")
@@ -114,11 +116,17 @@ def main():
         if world == 1 and a.gpus > 1:
             sys.exit(f"--gpus {a.gpus} needs one process per GPU: launch with python -m torch.distributed.run "
                      f"--nnodes=1 --nproc-per-node {a.gpus} --master-addr 127.0.0.1 bench.py --gpus {a.gpus} ...")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(ndev, 1)  # one rank per GPU; the modulo only matters for the gloo rehearsal below
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    backend = os.environ.get("GNC_BENCH_BACKEND", "nccl")  # "gloo": rehearse the N > 1 bookkeeping on a 1-GPU box
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
 
     native.load_library()
     w = synthetic.WORKLOADS[a.workload]
@@ -126,9 +134,9 @@ def main():
     if a.scaling == "weak":
         # every rank owns a full-size batch (different seed per rank: different graphs)
         synthetic.WORKLOADS[a.workload]["seed"] = w["seed"] + 100 * rank
-        batch, kw = synthetic.make_workload(a.workload)
+        batch, kw = synthetic.make_workload(a.workload, a.scale)
     else:
-        full, kw = synthetic.make_workload(a.workload)
+        full, kw = synthetic.make_workload(a.workload, a.scale)
         g0, g1 = shard_ranges(full.edge_ptr, world)[rank]
         batch = full.slice_graphs(g0, g1)
     torch.manual_seed(0)  # identical weights on every rank
@@ -185,7 +193,7 @@ def main():
     ksum = timers.summary()
 
     stats = torch.tensor([elapsed, float(batch.num_edges), float(batch.num_graphs), float(batch.num_nodes)],
-                         dtype=torch.float64, device=dev)
+                         dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         tmax = stats[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -211,7 +219,7 @@ def main():
             "unit": "edges/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": a.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{a.workload}: {w['desc']}", "graphs": int(tot_graphs), "nodes": int(tot_nodes),
+            "config": {"workload": f"{a.workload}: {w['desc']}" + ("" if a.scale == 1.0 else f" [scaled to {a.scale} of the graphs]"), "graphs": int(tot_graphs), "nodes": int(tot_nodes),
                        "edges": int(tot_edges), "n_blocks": n_blocks, "width": w["width"],
                        "step": "CSR build + GraphNet.forward, inputs resident in HBM" if a.mode == "forward" else
                                "CSR build + forward + CE loss + backward + flat grad all-reduce + Adam, inputs resident in HBM"},

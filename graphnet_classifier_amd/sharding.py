@@ -58,7 +58,12 @@ class FlatGradAllReduce:
                 self.flat[off:off + n].copy_(p.grad.reshape(-1))
             off += n
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)  # ONE collective per step
+            if self.flat.is_cuda and dist.get_backend(self.group) == "gloo":  # CPU rehearsal backend: stage through the host
+                host = self.flat.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                self.flat.copy_(host)
+            else:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)  # ONE collective per step (RCCL)
             self.flat.div_(dist.get_world_size(self.group))
         off = 0
         for p in self.params:
