@@ -95,6 +95,7 @@ struct BwdArgs {
   float* dx;                   // nullable: [rows, in_dim0] grad wrt the MATMUL part of the input
   int ld_dx;
   float* yhat;                 // [rows, out_dim] normalised pre-affine output (only with LayerNorm)
+  int dx_add_grad_out;         // add grad_out rows to dx (the residual path of a segment that is also the residual)
 };
 
 // HT = tiles of the hidden AND output width (both <= 64).  NMM / NADD as in mlp_resident.hip.
@@ -316,7 +317,27 @@ __global__ __launch_bounds__(BNT) void mlp_backward_data_kernel(const gnc_mlp_de
         f32x16 dxs[HT];
         zero_tiles<HT>(dxs);
         mma_transposed_from_regs<HT, HT>(dxs, g, wres + s * CH, i, h);  // columns wcol_s .. of W_0^T dz_0
-        emit(dxs, b.dx + d.seg[s].wcol, b.ld_dx, sv[s].width, row0);
+        if (b.dx_add_grad_out && s == NMM - 1) {  // residual path: + grad_out, read back as whole rows (L2 hits)
+          compiler_lds_barrier();
+          tiles_to_lds<HT>(dxs, abuf, i, h);
+          compiler_lds_barrier();
+          const int col = c4 * 4;
+          float* dst = b.dx + d.seg[s].wcol;
+          const int width = sv[s].width;
+          const bool vec = (width % 4 == 0) && (b.ld_dx % 4 == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0);
+          const int gc = col < b.ld_grad_out ? col : 0;
+#pragma unroll
+          for (int p = 0; p < NP; ++p) {
+            const int r = row0 + p * 4 + rs;
+            const int rc = r < rows ? r : rows - 1;
+            f32x4 v = *reinterpret_cast<const f32x4*>(abuf + (p * 4 + rs) * LDSW + col);
+            v += *reinterpret_cast<const f32x4*>(b.grad_out + (int64_t)rc * b.ld_grad_out + gc);
+            store_row_piece(dst + (int64_t)rc * b.ld_dx, col, v, r < rows && col < width, width, vec);
+          }
+          compiler_lds_barrier();
+        } else {
+          emit(dxs, b.dx + d.seg[s].wcol, b.ld_dx, sv[s].width, row0);
+        }
       }
     }
   }
@@ -996,6 +1017,11 @@ extern "C" int gnc_mlp_backward_supported(const gnc_mlp_desc_t* fwd) {
   return GNC_OK;
 }
 
+extern "C" int gnc_mlp_backward_dx_add_honoured(const gnc_mlp_desc_t* fwd) {
+  int nmm, nadd, T;
+  return (fwd && validate_desc(fwd, false) == GNC_OK && bwd_shape(*fwd, &nmm, &nadd, &T)) ? 1 : 0;
+}
+
 extern "C" int gnc_mlp_backward_f32(const gnc_mlp_bwd_desc_t* bd, void* stream_) {
   if (!bd) { gnc::set_error("gnc_mlp_backward_f32: null descriptor"); return GNC_ERR_INVALID_ARGUMENT; }
   const gnc_mlp_desc_t& d = bd->fwd;
@@ -1026,6 +1052,7 @@ extern "C" int gnc_mlp_backward_f32(const gnc_mlp_bwd_desc_t* bd, void* stream_)
   b.dx = bd->dx;
   b.ld_dx = bd->ld_dx;
   b.yhat = d.ln_gamma ? bd->yhat : nullptr;
+  b.dx_add_grad_out = (resident && bd->dx_add_grad_out) ? 1 : 0;
 
   if (!resident) {
     hipStream_t st = (hipStream_t)stream_;

@@ -266,11 +266,12 @@ def _edge_wsplit_backward_hip(ctx, grad_out):
     if not native.mlp_backward_supported(segments, wl, biases, ln, activation, e, e.size(0), modes):
         return None
     grad_out = grad_out.contiguous()
-    r = native.mlp_backward(segments, wl, biases, ln, grad_out, rows=e.size(0), modes=modes, need_dx=bool(need[1]))
+    r = native.mlp_backward(segments, wl, biases, ln, grad_out, rows=e.size(0), modes=modes, need_dx=bool(need[1]),
+                            residual=e)
     dz0 = r["dz"][0]
     grads = [None] * (2 + len(params))
-    if need[1]:
-        grads[1] = r["dx"] + grad_out  # through We, plus the residual path
+    if need[1]:  # through We, plus the residual path (folded into the kernel's dx when it can)
+        grads[1] = r["dx"] if r["residual_folded"] else r["dx"] + grad_out
     # node side: d(ps)[v] = sum of dz0 over edges with src == v, d(pd)[v] = ... dst == v
     csc_rowptr, csc_perm = topo.csc
     dps = native.scatter_sum_csr(dz0, csc_rowptr, csc_perm, topo.num_nodes)

@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 GNC_MAX_SEGMENTS = 4
 GNC_MAX_LINEAR = 8
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 ACTIVATIONS = {  # nn.<Name> accepted by the reference's MLP(activation=...) (models/MLP.py:21)
     "ReLU": 0, "Identity": 1, "Tanh": 2, "Sigmoid": 3, "SiLU": 4, "GELU": 5, "LeakyReLU": 6, "ELU": 7,
@@ -41,6 +41,7 @@ _SIGNATURES = {
     "gnc_mlp_forward_f32": (c_int32, [c_void_p, c_void_p]),
     "gnc_sizeof_mlp_bwd_desc": (c_size_t, []),
     "gnc_mlp_backward_supported": (c_int32, [c_void_p]),
+    "gnc_mlp_backward_dx_add_honoured": (c_int32, [c_void_p]),
     "gnc_mlp_backward_f32": (c_int32, [c_void_p, c_void_p]),
     "gnc_xty_partials": (c_int32, [c_int64]),
     "gnc_xty_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, c_void_p, c_int32, c_void_p]),
@@ -79,7 +80,7 @@ class MlpBwdDesc(Structure):
     _fields_ = [
         ("fwd", MlpDesc), ("grad_out", c_void_p), ("ld_grad_out", c_int32),
         ("act", c_void_p * GNC_MAX_LINEAR), ("dz", c_void_p * GNC_MAX_LINEAR),
-        ("dx", c_void_p), ("ld_dx", c_int32), ("yhat", c_void_p),
+        ("dx", c_void_p), ("ld_dx", c_int32), ("yhat", c_void_p), ("dx_add_grad_out", c_int32),
     ]
 
 
@@ -398,16 +399,21 @@ def mlp_backward_supported(segments, weights, biases, ln, activation, residual, 
 
 
 def mlp_backward(segments, weights, biases, ln, grad_out: torch.Tensor, rows: int | None = None, modes=None,
-                 need_dx: bool = True):
+                 need_dx: bool = True, residual: torch.Tensor | None = None):
     """Data path of the MLP backward (see include/gnc_hip.h, K8).  Returns a dict with
     ``act`` (inputs of Linear 1..L-1), ``dz`` (grads of every pre-activation, dz[-1] = pre-LayerNorm),
     ``dx`` ([rows, in_dim0] in weight-column order, or None) and ``yhat`` (or None)."""
     lib = load_library()
-    segs, w, b, _, rows, _ = _prepare_mlp(segments, weights, biases, None, rows, modes)
+    segs, w, b, residual, rows, _ = _prepare_mlp(segments, weights, biases, residual, rows, modes)
     dev = segs[0][0].device
     dummy = torch.empty(1, w[-1].size(0), device=dev)
     bd = MlpBwdDesc()
     bd.fwd = make_mlp_desc(segs, w, b, ln, "ReLU", 0.0, None, dummy, rows)
+    # residual given: ask the kernel to fold its gradient (grad_out) into the dx of the segment it came from
+    mm = [sg for sg in segs if sg[3] == SEG_MATMUL]
+    fold = (residual is not None and need_dx and mm[-1][1] is None and mm[-1][0].data_ptr() == residual.data_ptr()
+            and mm[-1][2] == w[-1].size(0) and lib.gnc_mlp_backward_dx_add_honoured(ctypes.byref(bd.fwd)) == 1)
+    bd.dx_add_grad_out = 1 if fold else 0
     g = _vector_rows(_rowmajor(grad_out))
     bd.grad_out, bd.ld_grad_out = g.data_ptr(), _ld(g)
     n_lin = len(w)
@@ -427,7 +433,7 @@ def mlp_backward(segments, weights, biases, ln, grad_out: torch.Tensor, rows: in
     with torch.cuda.device(dev):
         _check(_launch(f"mlp_backward_in{w[0].size(1)}_h{w[0].size(0)}_out{w[-1].size(0)}_L{n_lin}", g,
                        lambda: lib.gnc_mlp_backward_f32(ctypes.byref(bd), _stream(g)), flops), "gnc_mlp_backward_f32")
-    return {"act": act, "dz": dz, "dx": dx, "yhat": yhat, "_keep": (segs, w, b, g)}
+    return {"act": act, "dz": dz, "dx": dx, "yhat": yhat, "residual_folded": bool(fold), "_keep": (segs, w, b, g)}
 
 
 def xty(a: torch.Tensor, b: torch.Tensor):

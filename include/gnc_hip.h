@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GNC_ABI_VERSION 6
+#define GNC_ABI_VERSION 7
 
 enum {
   GNC_OK = 0,
@@ -201,10 +201,14 @@ typedef struct gnc_mlp_bwd_desc {
   float* dx;
   int32_t ld_dx;
   float* yhat;
+  int32_t dx_add_grad_out; /* 1: the LAST MATMUL segment is also the residual and out_dim equals its width: its dx
+                              columns get grad_out added in the kernel (honoured by the weights-resident variant;
+                              gnc_mlp_backward_dx_add_honoured() tells) */
 } gnc_mlp_bwd_desc_t;
 
 size_t gnc_sizeof_mlp_bwd_desc(void);
 int gnc_mlp_backward_supported(const gnc_mlp_desc_t* fwd /* host */);
+int gnc_mlp_backward_dx_add_honoured(const gnc_mlp_desc_t* fwd /* host */); /* 1 / 0 */
 int gnc_mlp_backward_f32(const gnc_mlp_bwd_desc_t* desc /* host */, void* stream);
 int gnc_xty_partials(int64_t rows);
 int gnc_xty_f32(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t rows, int32_t M, int32_t K,
