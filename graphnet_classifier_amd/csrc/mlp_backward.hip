@@ -193,20 +193,31 @@ __global__ __launch_bounds__(BNT) void mlp_backward_data_kernel(const gnc_mlp_de
     // ------------------------------------------------------------------ forward recompute
     f32x16 hid[HT];
     init_bias<HT>(hid, pbuf, h);
+    f32x4 gpre[NP];  // grad_out rows of this tile: requested early, consumed after the forward recompute
     {
-      f32x4 pre[NP], pre2[NP];
+      f32x4 pre[NP], pre2[NP], pre3[NP];
+      load_rows(pre, sv[0].ptr, sv[0].ld, load_idx(wt, sv[0]));
 #pragma unroll
       for (int s = 0; s < NMM; ++s) {
-        load_rows(pre, sv[s].ptr, sv[s].ld, load_idx(wt, sv[s]));
         stage(pre, sv[s].width);
+        // request the next step's rows (and, at the last MATMUL step, the additive gathers and grad_out) before the MFMAs
+        if (s + 1 < NMM) {
+          load_rows(pre, sv[s + 1 < NMM ? s + 1 : 0].ptr, sv[s + 1 < NMM ? s + 1 : 0].ld, load_idx(wt, sv[s + 1 < NMM ? s + 1 : 0]));
+        } else {
+          if constexpr (NADD > 0) {
+            load_rows(pre2, sv[NMM].ptr, sv[NMM].ld, load_idx(wt, sv[NMM]));
+            load_rows(pre3, sv[NMM + 1].ptr, sv[NMM + 1].ld, load_idx(wt, sv[NMM + 1]));
+          }
+          int r = row0 + (lane & 31);
+          r = r < rows ? r : rows - 1;
+          load_rows(gpre, b.grad_out, b.ld_grad_out, r);
+        }
         mma_chunk_from_lds<HT>(hid, abuf, wres + s * CH, (sv[s].width + 7) >> 3, i, h);
       }
       if constexpr (NADD > 0) {
-        load_rows(pre, sv[NMM].ptr, sv[NMM].ld, load_idx(wt, sv[NMM]));
-        load_rows(pre2, sv[NMM + 1].ptr, sv[NMM + 1].ld, load_idx(wt, sv[NMM + 1]));
 #pragma unroll
-        for (int p = 0; p < NP; ++p) pre[p] += pre2[p];
-        stage(pre, sv[NMM].width);
+        for (int p = 0; p < NP; ++p) pre2[p] += pre3[p];
+        stage(pre2, sv[NMM].width);
         add_tile_from_lds<HT>(hid, abuf, i, h);
       }
     }
@@ -229,11 +240,7 @@ __global__ __launch_bounds__(BNT) void mlp_backward_data_kernel(const gnc_mlp_de
     // ------------------------------------------------------------------ grad of the pre-LayerNorm output
     f32x16 g[HT];
     {
-      f32x4 pre[NP];
-      int r = row0 + (lane & 31);
-      r = r < rows ? r : rows - 1;
-      load_rows(pre, b.grad_out, b.ld_grad_out, r);
-      stage(pre, out_dim);
+      stage(gpre, out_dim);
       tile_from_lds<HT>(g, abuf, i, h);
       compiler_lds_barrier();
     }
