@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Timing of the device-side superpixel graph build (post-SLIC part) against the oracle's restatement of the
-reference's O(S^2) dilation loop, on a synthetic Voronoi label image."""
+"""Timing of the device-side superpixel graph build (post-SLIC part) on synthetic Voronoi label images.
+(The CPU comparison quoted in DESIGN.md was taken with the test-suite oracle; tools never import oracle/.)"""
 import os
 import sys
 import time
@@ -10,7 +10,6 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from graphnet_classifier_amd import image_to_graph as I2G  # noqa: E402
-from oracle import image_graph_oracle as IO  # noqa: E402
 
 rng = np.random.default_rng(0)
 for size, nseg in ((32, 100), (128, 100), (256, 400)):
@@ -25,8 +24,4 @@ for size, nseg in ((32, 100), (128, 100), (256, 400)):
         x, pos, ei = I2G.superpixel_graph_from_labels(img, seg)
     torch.cuda.synchronize()
     gpu = (time.perf_counter() - t0) / 10
-    t0 = time.perf_counter()
-    rx, rpos, rei = IO.superpixel_graph_from_labels(img, seg)
-    cpu = time.perf_counter() - t0
-    print(f"R={size} segments={x.size(0)} edges={ei.size(1)}: device {gpu*1e3:.2f} ms (incl. H2D + 1 sync), "
-          f"oracle/CPU {cpu*1e3:.0f} ms, equal edges: {np.array_equal(ei.cpu().numpy(), rei)}", flush=True)
+    print(f"R={size} segments={x.size(0)} edges={ei.size(1)}: device {gpu*1e3:.2f} ms (incl. H2D + 1 sync)", flush=True)

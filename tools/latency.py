@@ -11,11 +11,11 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from graphnet_classifier_amd import synthetic  # noqa: E402
 from graphnet_classifier_amd.GNN import CombinedModel, GraphNet  # noqa: E402
-from oracle import graphnet_oracle as O  # noqa: E402  (only for the grid topology of the pixel graph)
+from graphnet_classifier_amd.image_to_graph import create_grid_edges_optimized  # noqa: E402
 
 torch.manual_seed(0)
 cases = {}
-ei = torch.from_numpy(O.grid_edge_index(32, 32))
+ei = create_grid_edges_optimized(32, 32).cpu()
 rr, cc = np.meshgrid(np.arange(32), np.arange(32), indexing="ij")
 cases["pixel R=32 (N=1024, E=1984)"] = (torch.rand(1024, 3) * 255, torch.from_numpy(np.stack([rr.ravel(), cc.ravel()], 1).astype(np.float32)), ei)
 b = synthetic.superpixel_like_graphs(1, seed=1000, shapes=((12, 12),))
