@@ -330,18 +330,35 @@ class CombinedModel(nn.Module):
         logits = self.classifier(y)
         return logits if back == dev else logits.to(back)
 
-    def forward_batched(self, x, pos, edge_index, num_graphs: int):
-        """Block-diagonal batch of ``num_graphs`` graphs of exactly ``num_nodes`` nodes each
-        (graph g owns node rows g*num_nodes ...): one GraphNet pass, then the read-out as a
-        [G, num_nodes*out_dim] GEMM.  Equals ``num_graphs`` independent ``forward`` calls; the
-        reference has no batching (main.py:60)."""
+    def forward_batched(self, x, pos, edge_index, num_graphs: int | None = None, graph_ptr: Tensor | None = None):
+        """Block-diagonal batch: one GraphNet pass over all graphs, then the read-out as one
+        [G, num_nodes*out_dim] GEMM.  The reference has no batching (main.py:60, SURVEY.md section 2.4-2);
+        this equals G independent ``forward`` calls.
+
+        * ``num_graphs`` given: every graph has exactly ``num_nodes`` nodes (graph g owns rows g*num_nodes ...).
+        * ``graph_ptr`` [G+1] given (node offsets): graphs of ANY size.  The reference's read-out is only
+          defined for N == num_nodes (its superpixel path crashes otherwise); the
+          build-side rule, a stated deviation, is: the first ``num_nodes`` nodes of a graph feed ``fc1``, a
+          smaller graph is zero-padded.  With N == num_nodes for every graph both modes coincide.
+        """
         dev = require_gpu_param(self.classifier.fc1.weight, "CombinedModel")
         back = x.device
-        if x.size(0) != num_graphs * self.num_nodes:
-            raise ValueError(f"expected {num_graphs} x {self.num_nodes} node rows, got {x.size(0)}")
         x = x.to(device=dev, dtype=torch.float32)
         pos = pos.to(device=dev, dtype=torch.float32)
         topo = get_topology(edge_index, x.size(0), dev)
-        y = self.graph_net.forward_device(x, pos, topo).view(num_graphs, -1)
-        logits = self.classifier(y)
+        y = self.graph_net.forward_device(x, pos, topo)  # [N_total, out_dim]
+        od = self.graph_net.out_dim
+        if graph_ptr is None:
+            if num_graphs is None or x.size(0) != num_graphs * self.num_nodes:
+                raise ValueError(f"expected num_graphs x {self.num_nodes} node rows (got {x.size(0)}); pass graph_ptr "
+                                 f"for graphs of other sizes")
+            feats = y.view(num_graphs, -1)
+        else:
+            gp = graph_ptr.to(device=dev, dtype=torch.int64)
+            start, size = gp[:-1], gp[1:] - gp[:-1]
+            k = torch.arange(self.num_nodes, device=dev)
+            valid = k[None, :] < size[:, None]                                   # [G, num_nodes]
+            rows = (start[:, None] + k[None, :]).clamp_(max=max(y.size(0) - 1, 0))
+            feats = (y[rows] * valid[..., None]).reshape(gp.numel() - 1, self.num_nodes * od)
+        logits = self.classifier(feats)
         return logits if back == dev else logits.to(back)

@@ -164,6 +164,26 @@ def test_combined_forward_batched_equals_per_graph(G):
             assert max_abs(lb[k], l1) < 2e-6
 
 
+def test_forward_batched_variable_size_readout_policy(G):
+    """graph_ptr mode: first num_nodes nodes feed fc1, smaller graphs are zero-padded (stated deviation; the
+    reference's read-out only exists for N == num_nodes)."""
+    from graphnet_classifier_amd import synthetic as S
+    batch = S.superpixel_like_graphs(5, seed=21)  # 144 / 156 / 169 nodes
+    nn_ = 156
+    torch.manual_seed(8)
+    m = G.CombinedModel(G.GraphNet(**S.graphnet_kwargs(32, 2)), num_nodes=nn_, classes=2)
+    with torch.no_grad():
+        lb = m.forward_batched(batch.x, batch.pos, batch.edge_index, graph_ptr=batch.graph_ptr)
+        assert lb.shape == (5, 2)
+        for gi in range(5):
+            s = batch.slice_graphs(gi, gi + 1)
+            y = m.graph_net(s.x, s.pos, s.edge_index).flatten()
+            v = torch.zeros(nn_)
+            v[:min(nn_, y.numel())] = y[:nn_]
+            ref = m.classifier(v.to(DEV)).cpu()
+            assert max_abs(lb[gi], ref) < 2e-6
+
+
 def test_edge_order_invariance(G):
     """Permuting the edge list changes only the per-destination summation order (fp32 noise)."""
     from graphnet_classifier_amd import synthetic as S
