@@ -181,37 +181,72 @@ __device__ __forceinline__ void mma_chunk_from_regs(f32x16 (&dst)[TO], const f32
   }
 }
 
+// x(lane) + x(lane ^ 32) in every lane, on the VALU: gfx950's v_permlane32_swap exchanges the upper half of
+// one register with the lower half of another (no LDS round trip like ds_bpermute / __shfl_xor).
+__device__ __forceinline__ float add_halves(float x) {
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);  // lower-half value + upper-half value, in that order
+}
+
 // LayerNorm over the out_dim features of each data row: registers + one cross-half exchange.
+// fp32 MFMA and VALU instructions do NOT overlap on a gfx950 SIMD (tools/mfma_ceiling.hip: one 32x32x2 MFMA
+// + k VALU = 64 + ~3..5k cycles), so the instruction count here is kernel time: packed fp32 math, no
+// per-feature selects (features >= out_dim hold exact zeros - zero weight rows, zero bias - so they drop out
+// of the sum; their deviations are cleared before the variance when the width is not 32*OT), 1/n as a
+// multiplier and v_rsq_f32 (1 ulp): ~85 VALU per 32 rows instead of ~310.
 template <int OT>
 __device__ __forceinline__ void layer_norm_tiles(f32x16 (&o)[OT], const float* pg, const float* pbt, int out_dim,
                                                  float eps, int h) {
-  float s = 0.f;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const float inv_n = 1.f / (float)out_dim;  // loop-invariant for the caller's tile loop
+  f32x2 sa = {0.f, 0.f}, sb = {0.f, 0.f};
 #pragma unroll
   for (int t = 0; t < OT; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s += (feat_of(t, r, h) < out_dim) ? o[t][r] : 0.f;
-  s += __shfl_xor(s, 32, 64);
-  const float mean = s / (float)out_dim;
-  float v = 0.f;
-#pragma unroll
-  for (int t = 0; t < OT; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float dlt = o[t][r] - mean;
-      v += (feat_of(t, r, h) < out_dim) ? dlt * dlt : 0.f;
+    for (int q = 0; q < 4; ++q) {
+      sa += f32x2{o[t][4 * q + 0], o[t][4 * q + 1]};
+      sb += f32x2{o[t][4 * q + 2], o[t][4 * q + 3]};
     }
-  v += __shfl_xor(v, 32, 64);
-  const float rstd = 1.f / sqrtf(v / (float)out_dim + eps);
+  const float mean = add_halves((sa.x + sa.y) + (sb.x + sb.y)) * inv_n;
+  const f32x2 m2 = {mean, mean};
+#pragma unroll
+  for (int t = 0; t < OT; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x2 da = f32x2{o[t][4 * q + 0], o[t][4 * q + 1]} - m2;
+      const f32x2 db = f32x2{o[t][4 * q + 2], o[t][4 * q + 3]} - m2;
+      o[t][4 * q + 0] = da.x; o[t][4 * q + 1] = da.y; o[t][4 * q + 2] = db.x; o[t][4 * q + 3] = db.y;
+    }
+  if (out_dim != OT * 32) {  // wave-uniform and rare: clear the deviations of the padding features
+#pragma unroll
+    for (int t = 0; t < OT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[t][r] = (feat_of(t, r, h) < out_dim) ? o[t][r] : 0.f;
+  }
+  f32x2 va = {0.f, 0.f}, vb = {0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < OT; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x2 da = {o[t][4 * q + 0], o[t][4 * q + 1]}, db = {o[t][4 * q + 2], o[t][4 * q + 3]};
+      va = __builtin_elementwise_fma(da, da, va);
+      vb = __builtin_elementwise_fma(db, db, vb);
+    }
+  const float var = add_halves((va.x + va.y) + (vb.x + vb.y)) * inv_n;
+  const float rstd = __frsqrt_rn(var + eps);
+  const f32x2 r2 = {rstd, rstd};
 #pragma unroll
   for (int t = 0; t < OT; ++t)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const f32x4 gm = *reinterpret_cast<const f32x4*>(pg + 32 * t + 8 * q + 4 * h);
       const f32x4 bt = *reinterpret_cast<const f32x4*>(pbt + 32 * t + 8 * q + 4 * h);
-      o[t][4 * q + 0] = (o[t][4 * q + 0] - mean) * rstd * gm.x + bt.x;
-      o[t][4 * q + 1] = (o[t][4 * q + 1] - mean) * rstd * gm.y + bt.y;
-      o[t][4 * q + 2] = (o[t][4 * q + 2] - mean) * rstd * gm.z + bt.z;
-      o[t][4 * q + 3] = (o[t][4 * q + 3] - mean) * rstd * gm.w + bt.w;
+      const f32x2 ya = __builtin_elementwise_fma(f32x2{o[t][4 * q + 0], o[t][4 * q + 1]}, f32x2{gm.x, gm.y} * r2,
+                                                 f32x2{bt.x, bt.y});
+      const f32x2 yb = __builtin_elementwise_fma(f32x2{o[t][4 * q + 2], o[t][4 * q + 3]}, f32x2{gm.z, gm.w} * r2,
+                                                 f32x2{bt.z, bt.w});
+      o[t][4 * q + 0] = ya.x; o[t][4 * q + 1] = ya.y; o[t][4 * q + 2] = yb.x; o[t][4 * q + 3] = yb.y;
     }
 }
 
