@@ -357,6 +357,33 @@ __device__ __forceinline__ void hidden_store_b32(float* p, float v, unsigned lon
       : "memory");
 }
 
+// ---- row windows: buffer addressing ------------------------------------------------------------------
+// A "window" is a raw buffer descriptor (4 SGPRs, built by the scalar unit) that starts at row `row0` of a
+// row-major table and ends where the table ends.  Accesses name a per-lane BYTE offset inside the window,
+// so the vector unit spends nothing on addresses (flat global_load needs a 64-bit v_mad / v_lshl_add per
+// access, and fp32 MFMA time and VALU time add up on gfx950), and the hardware bounds check replaces the
+// tail handling: loads past the table's end return 0, stores past it are dropped.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_window(const float* base, int64_t row0, int64_t rows, int ld) {
+  int64_t rem = (rows - row0) * (int64_t)ld * 4;  // bytes from the window's first row to the end of the table
+  rem = rem < 0 ? 0 : (rem > 0xffffffffll ? 0xffffffffll : rem);
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + row0 * ld), 0, (int)(uint32_t)rem, 0x00020000);
+}
+
+__device__ __forceinline__ f32x4 window_load(__amdgpu_buffer_rsrc_t w, uint32_t byte_off) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  return __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(w, byte_off, 0, 0));
+}
+
+// 16-B store into a window, issued behind the compiler's back (same reason as hidden_store_b128)
+__device__ __forceinline__ void hidden_window_store(f32x4 v, uint32_t byte_off, __amdgpu_buffer_rsrc_t w) {
+  asm volatile(
+      "buffer_store_dwordx4 %0, %1, %2, 0 offen\n\t"
+      "s_nop 1"
+      :
+      : "v"(v), "v"(byte_off), "s"(w)
+      : "memory");
+}
+
 // one output row group: 16-B store when the row layout allows it, else up to four masked scalar stores
 __device__ __forceinline__ void store_row_piece(float* rowp, int col, f32x4 v, bool row_ok, int out_dim, bool vec_out) {
   if (vec_out) {
@@ -440,6 +467,7 @@ struct SegView {  // wave-uniform view of one segment
   const int32_t* index;
   int ld;
   int width;
+  uint32_t bytes;  // gathered tables: size of the table (bound of the buffer window), < 4 GiB
 };
 
 

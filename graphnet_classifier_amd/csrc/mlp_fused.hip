@@ -200,6 +200,10 @@ int gnc_mlp::validate_desc(const gnc_mlp_desc_t* d, bool check_ptrs) {
       return GNC_ERR_INVALID_ARGUMENT;
     }
     if (check_ptrs && d->rows > 0 && !d->seg[s].ptr) { gnc::set_error("gnc_mlp: segment %d null", s); return GNC_ERR_INVALID_ARGUMENT; }
+    if (d->seg[s].index && d->seg[s].table_rows < 0) {
+      gnc::set_error("gnc_mlp: segment %d states a table of %lld rows", s, (long long)d->seg[s].table_rows);
+      return GNC_ERR_INVALID_ARGUMENT;
+    }
     if (d->seg[s].mode == GNC_SEG_ADD) {
       if (d->seg[s].width != d->out_dim[0]) {
         gnc::set_error("gnc_mlp: additive segment %d has width %d, first Linear has %d outputs", s, d->seg[s].width, d->out_dim[0]);

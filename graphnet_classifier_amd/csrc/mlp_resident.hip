@@ -22,16 +22,44 @@
 //     output stores are therefore issued from inline asm (invisible to that bookkeeping;
 //     loads still complete in order among themselves, so the compiler's counted waits stay
 //     correct - they can only over-wait).
-//   * every load is unconditional: row ids are clamped instead of predicated (rows past the end
-//     produce values that are never stored), so there is no exec-masked VMEM in the loop.
+//   * every load is unconditional: row-ordered tables are read through per-tile buffer windows
+//     (rows past the end read as 0, rows past the end are never stored - the hardware bounds check
+//     does both), gather ids are clamped; there is no exec-masked VMEM in the loop.
+// fp32 MFMA time and VALU time ADD UP on a gfx950 SIMD (tools/mfma_ceiling.hip), so the loop keeps the
+// vector unit out of address arithmetic: windows are built by the scalar unit, per-lane offsets are
+// loop constants, gathered rows cost one v_lshl_add_u64 each.
 // Requirements checked by the launcher (anything else runs the streaming kernel): ReLU,
 // all tables / weights / output 16-B aligned with leading dimensions % 4 == 0, every segment
-// <= 64 columns, MATMUL segments listed before ADD segments, out width % 4 == 0, rows < 2^31.
+// <= 64 columns, MATMUL segments listed before ADD segments, rows < 2^31, gathered tables with a stated
+// size (table_rows) below 4 GiB.
 #include <stdlib.h>
 
 #include "mlp_device.h"
 
 using namespace gnc_mlp;
+
+// Phase probe (build with `make PROBE=1`): every wave sums the shader-clock cycles (s_memtime) it spends
+// in each phase of its tile loop and leaves them, its total and the 100 MHz wall clock in gnc_phase_probe;
+// tools/profile_mlp.py reads them back.  Off in the shipped library.
+#ifdef GNC_PHASE_PROBE
+__device__ unsigned long long gnc_phase_probe[4096 * 12];
+extern "C" int gnc_phase_probe_read(void* dst, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(gnc_phase_probe), bytes);
+}
+#define PROBE_BEGIN() unsigned long long pr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pr_tp, pr_tn; \
+  const unsigned long long pr_c0 = __builtin_readcyclecounter(), pr_w0 = wall_clock64()
+#define PROBE_TILE() pr_tp = __builtin_readcyclecounter()
+#define PROBE(k) do { pr_tn = __builtin_readcyclecounter(); pr_acc[k] += pr_tn - pr_tp; pr_tp = pr_tn; } while (0)
+#define PROBE_END() do { if ((threadIdx.x & 63) == 0) {                                                      \
+    unsigned long long* o = gnc_phase_probe + (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 12;    \
+    for (int k = 0; k < 8; ++k) o[k] = pr_acc[k];                                                            \
+    o[8] = __builtin_readcyclecounter() - pr_c0; o[9] = wall_clock64() - pr_w0; } } while (0)
+#else
+#define PROBE_BEGIN() do {} while (0)
+#define PROBE_TILE() do {} while (0)
+#define PROBE(k) do {} while (0)
+#define PROBE_END() do {} while (0)
+#endif
 
 namespace {
 
@@ -43,7 +71,7 @@ constexpr int RNT = RWAVES * 64;
 // the LAST MATMUL step (no index): its rows are kept in registers instead of being re-read.
 template <int HT, int OT, int NMM, int NADD, bool RESREG>
 __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t d, const int num_wtiles,
-                                                           const int total_chunks, const int flags) {
+                                                           const int total_chunks) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int WT = HT > OT ? HT : OT;
   constexpr int CH = WT * 32 * LDSW;  // floats per resident weight chunk
@@ -84,35 +112,39 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
 
   SegView sv[NS];
 #pragma unroll
-  for (int s = 0; s < NS; ++s) sv[s] = {d.seg[s].ptr, d.seg[s].index, d.seg[s].ld, d.seg[s].width};
+  for (int s = 0; s < NS; ++s) sv[s] = {d.seg[s].ptr, d.seg[s].index, d.seg[s].ld, d.seg[s].width,
+                                          (uint32_t)(d.seg[s].table_rows * d.seg[s].ld * 4)};  // launcher: < 4 GiB
 
   // ---- per-wave pipeline -----------------------------------------------------------------------
   const int total_waves = (int)gridDim.x * RWAVES;
   const int last_wt = num_wtiles - 1;
-  const bool NT_STREAM = (flags & 1) != 0;
 
-  // table row of tile row (lane & 31); clamped so the load is always legal
-  auto load_idx = [&](int wt, const SegView& s) -> int {
+  // Gathered segments: table row of tile row (lane & 31), fetched one tile ahead and NOT touched until the
+  // gather is issued (any use makes the compiler wait for it and, vmcnt being in order, for every load issued
+  // before it); clamped so the id load is always legal.  Row-ordered segments need no ids at all.
+  auto row_offset = [&](int wt, const SegView& s) -> uint32_t {
+    if (s.index == nullptr) return 0;
     const int wtc = wt < last_wt ? wt : last_wt;
     int r = wtc * RPW + (lane & 31);
     r = r < rows ? r : rows - 1;
-    return s.index ? s.index[r] : r;
+    return (uint32_t)s.index[r];
   };
-  // the step's rows: lane (rs, c4) gets 16 B of row p*4+rs for p = 0..7; no predication
-  auto load_rows = [&](f32x4 (&pre)[NP], const SegView& s, int idxv) {
+  // the step's rows: lane (rs, c4) gets 16 B of row p*4+rs for p = 0..7; no predication anywhere.
+  //   row-ordered table: one window per tile (SALU), per-lane byte offsets are loop constants, rows past
+  //                      the end read as 0;
+  //   gathered table:    the row's offset arrives by ds_bpermute, one v_lshl_add_u64 per access.
+  auto load_rows = [&](f32x4 (&pre)[NP], const SegView& s, int wt, uint32_t off) {
     const int col = c4 * 4 < s.ld ? c4 * 4 : 0;
-    if (s.index == nullptr && NT_STREAM) {  // rows read once, in order: keep them out of L2 / MALL
+    if (s.index == nullptr) {
+      const __amdgpu_buffer_rsrc_t w = row_window(s.ptr, (int64_t)wt * RPW, rows, s.ld);
+      const uint32_t lane_off = (uint32_t)(rs * s.ld + col) * 4u;
 #pragma unroll
-      for (int p = 0; p < NP; ++p) {
-        const int tr = __shfl(idxv, p * 4 + rs, 64);
-        pre[p] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(s.ptr + (int64_t)tr * s.ld + col));
-      }
+      for (int p = 0; p < NP; ++p) pre[p] = window_load(w, lane_off + (uint32_t)(p * 16) * (uint32_t)s.ld);
     } else {
+      const __amdgpu_buffer_rsrc_t w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s.ptr), 0, (int)s.bytes, 0x00020000);
+      const uint32_t row_bytes = off * (uint32_t)(s.ld * 4);  // byte offset of this lane's tile row, once per tile
 #pragma unroll
-      for (int p = 0; p < NP; ++p) {
-        const int tr = __shfl(idxv, p * 4 + rs, 64);
-        pre[p] = *reinterpret_cast<const f32x4*>(s.ptr + (int64_t)tr * s.ld + col);
-      }
+      for (int p = 0; p < NP; ++p) pre[p] = window_load(w, (uint32_t)__shfl((int)row_bytes, p * 4 + rs, 64) + (uint32_t)(col * 4));
     }
   };
   // registers -> the wave's LDS tile; columns at or beyond the segment width become zero
@@ -136,58 +168,77 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
 
   int wt = (int)blockIdx.x * RWAVES + wave;
   f32x4 cur[NP];                  // rows of the step about to be staged
-  f32x4 keep[RESREG ? NP : 1];    // residual rows (copy of the last MATMUL step)
   f32x4 addA[NADD ? NP : 1], addB[NADD ? NP : 1];
-  // gather ids: id0 = segment 0 of the NEXT tile, ids[s>=1] = segment s of the CURRENT tile
-  int ids[NS];
-  load_rows(cur, sv[0], load_idx(wt, sv[0]));
+  // row offsets of gathered segments: off0 = segment 0 of the NEXT tile, offs[s>=1] = segment s of the CURRENT tile
+  uint32_t offs[NS];
+  load_rows(cur, sv[0], wt, row_offset(wt, sv[0]));
 #pragma unroll
-  for (int s = 1; s < NS; ++s) ids[s] = load_idx(wt, sv[s]);
-  int id0 = load_idx(wt + total_waves, sv[0]);
+  for (int s = 1; s < NS; ++s) offs[s] = row_offset(wt, sv[s]);
+  uint32_t off0 = row_offset(wt + total_waves, sv[0]);
 
+  const int col_out = c4 * 4;
+  const bool vec_out = (out_dim % 4 == 0) && (d.ld_out % 4 == 0) && ((reinterpret_cast<uintptr_t>(d.out) & 15u) == 0);
+  const uint32_t out_lane_off = (uint32_t)(rs * d.ld_out + col_out) * 4u;
+  const uint32_t res_lane_off = (uint32_t)(rs * d.ld_residual + (col_out < d.ld_residual ? col_out : 0)) * 4u;
+
+  PROBE_BEGIN();
   while (wt < num_wtiles) {
+    PROBE_TILE();
     const int row0 = wt * RPW;
     const int nwt = wt + total_waves;
 
     // ------------------------------------------------------------------ first Linear
     f32x16 hid[HT];
+    f32x16 res[RESREG ? HT : 1];  // residual rows in accumulator layout (read back from the staged tile)
     init_bias<HT>(hid, pbuf, h);
 #pragma unroll
     for (int s = 0; s < NMM; ++s) {
       stage(cur, sv[s].width);
-      if constexpr (RESREG) if (s == NMM - 1) {
-#pragma unroll
-        for (int p = 0; p < NP; ++p) keep[p] = cur[p];
-      }
+      PROBE(0);  // wait for the step's rows + staging
       // request what comes next before the MFMAs of this step start
       if (s + 1 < NMM) {
-        load_rows(cur, sv[s + 1 < NMM ? s + 1 : 0], ids[s + 1 < NMM ? s + 1 : 0]);
-        ids[s + 1 < NMM ? s + 1 : 0] = load_idx(nwt, sv[s + 1 < NMM ? s + 1 : 0]);
+        load_rows(cur, sv[s + 1 < NMM ? s + 1 : 0], wt, offs[s + 1 < NMM ? s + 1 : 0]);
+        offs[s + 1 < NMM ? s + 1 : 0] = row_offset(nwt, sv[s + 1 < NMM ? s + 1 : 0]);
       } else {
         if constexpr (NADD > 0) {
-          load_rows(addA, sv[NMM], ids[NMM]);
-          load_rows(addB, sv[NMM + 1], ids[NMM + 1]);
-          ids[NMM] = load_idx(nwt, sv[NMM]);
-          ids[NMM + 1] = load_idx(nwt, sv[NMM + 1]);
+          load_rows(addA, sv[NMM], wt, offs[NMM]);
+          load_rows(addB, sv[NMM + 1], wt, offs[NMM + 1]);
+          offs[NMM] = row_offset(nwt, sv[NMM]);
+          offs[NMM + 1] = row_offset(nwt, sv[NMM + 1]);
         } else {
-          load_rows(cur, sv[0], id0);
-          id0 = load_idx(nwt + total_waves, sv[0]);
+          load_rows(cur, sv[0], nwt, off0);
+          off0 = row_offset(nwt + total_waves, sv[0]);
         }
       }
       mma_chunk_from_lds<HT>(hid, abuf, wres + s * CH, (sv[s].width + 7) >> 3, i, h);
+      if constexpr (RESREG) if (s == NMM - 1) {
+#pragma unroll
+        for (int t = 0; t < HT; ++t)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(abuf + i * LDSW + 32 * t + 8 * q + 4 * h);
+            res[t][4 * q + 0] = v.x; res[t][4 * q + 1] = v.y; res[t][4 * q + 2] = v.z; res[t][4 * q + 3] = v.w;
+          }
+      }
+      PROBE(1);  // load issue + first-Linear MFMAs
     }
     if constexpr (NADD > 0) {
       f32x4 sum[NP];
 #pragma unroll
       for (int p = 0; p < NP; ++p) sum[p] = addA[p] + addB[p];
       stage(sum, sv[NMM].width);
-      load_rows(cur, sv[0], id0);  // next tile's first step: the rest of this tile to land
-      id0 = load_idx(nwt + total_waves, sv[0]);
+      load_rows(cur, sv[0], nwt, off0);  // next tile's first step: the rest of this tile to land
+      off0 = row_offset(nwt + total_waves, sv[0]);
       add_tile_from_lds<HT>(hid, abuf, i, h);
+      PROBE(2);  // wait for the gathered rows + ADD step
     }
 
     if (L == 1) {  // plain projection
       if (d.ln_gamma) layer_norm_tiles<HT>(hid, pbuf + L * PSTRIDE, pbuf + (L + 1) * PSTRIDE, out_dim, d.ln_eps, h);
+      if constexpr (RESREG) {
+#pragma unroll
+        for (int t = 0; t < HT; ++t) hid[t] += res[t];
+      }
       compiler_lds_barrier();
       tiles_to_lds<HT>(hid, abuf, i, h);
     } else {
@@ -201,13 +252,20 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
 #pragma unroll
         for (int t = 0; t < HT; ++t) hid[t] = nxt[t];
       }
+      PROBE(3);  // hidden Linears
       // ---------------------------------------------------------------- last Linear, LayerNorm
       f32x16 o[OT];
       init_bias<OT>(o, pbuf + (L - 1) * PSTRIDE, h);
       mma_chunk_from_regs<HT, OT>(o, hid, wres + (NMM + L - 2) * CH, 0, d.in_dim[L - 1], i, h);
+      PROBE(4);  // last Linear
       if (d.ln_gamma) layer_norm_tiles<OT>(o, pbuf + L * PSTRIDE, pbuf + (L + 1) * PSTRIDE, out_dim, d.ln_eps, h);
+      if constexpr (RESREG) {
+#pragma unroll
+        for (int t = 0; t < OT && t < HT; ++t) o[t] += res[t < HT ? t : 0];
+      }
       compiler_lds_barrier();
       tiles_to_lds<OT>(o, abuf, i, h);
+      PROBE(5);  // LayerNorm + residual + transpose out
     }
     compiler_lds_barrier();
     // The compiler's counted vmcnt waits do not know about the asm stores below; make it collect the
@@ -218,34 +276,34 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
 
     // ------------------------------------------------------------------ epilogue: whole rows out
     {
-      const int col = c4 * 4;
-      const bool col_ok = col < out_dim;
-      const bool vec_out = (out_dim % 4 == 0) && (d.ld_out % 4 == 0) && ((reinterpret_cast<uintptr_t>(d.out) & 15u) == 0);
       f32x4 outv[NP];
 #pragma unroll
-      for (int p = 0; p < NP; ++p) {
-        outv[p] = *reinterpret_cast<const f32x4*>(abuf + (p * 4 + rs) * LDSW + col);
-        if constexpr (RESREG) outv[p] += keep[p];
+      for (int p = 0; p < NP; ++p) outv[p] = *reinterpret_cast<const f32x4*>(abuf + (p * 4 + rs) * LDSW + col_out);
+      if (!RESREG && d.residual) {  // rows this tile has just read: L2 hits; rows past the end read as 0
+        const __amdgpu_buffer_rsrc_t rw = row_window(d.residual, row0, rows, d.ld_residual);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) outv[p] += window_load(rw, res_lane_off + (uint32_t)(p * 16) * (uint32_t)d.ld_residual);
       }
-      if (!RESREG && d.residual) {  //  // rows this tile has just read: L2 hits; unconditional, clamped
-        const int rc = col < d.ld_residual ? col : 0;
+      if (vec_out) {  // rows past the end are dropped by the window's bounds check
+        const __amdgpu_buffer_rsrc_t ow = row_window(d.out, row0, rows, d.ld_out);
+        if (col_out < out_dim) {
+#pragma unroll
+          for (int p = 0; p < NP; ++p) hidden_window_store(outv[p], out_lane_off + (uint32_t)(p * 16) * (uint32_t)d.ld_out, ow);
+        }
+      } else {
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-          int r = row0 + p * 4 + rs;
-          r = r < rows ? r : rows - 1;
-          outv[p] += *reinterpret_cast<const f32x4*>(d.residual + (int64_t)r * d.ld_residual + rc);
+          const int r = row0 + p * 4 + rs;
+          store_row_piece(d.out + (int64_t)(r < rows ? r : rows - 1) * d.ld_out, col_out, outv[p], r < rows && col_out < out_dim,
+                          out_dim, false);
         }
-      }
-#pragma unroll
-      for (int p = 0; p < NP; ++p) {
-        const int r = row0 + p * 4 + rs;
-        store_row_piece(d.out + (int64_t)(r < rows ? r : rows - 1) * d.ld_out, col, outv[p], r < rows && col_ok, out_dim,
-                        vec_out);
       }
     }
     compiler_lds_barrier();
+    PROBE(6);  // epilogue: rows out
     wt = nwt;
   }
+  PROBE_END();
 }
 
 template <int HT, int OT, int NMM, int NADD, bool RESREG>
@@ -262,9 +320,8 @@ int launch(const gnc_mlp_desc_t& d, int total_chunks, size_t smem, hipStream_t s
   const int64_t num_wtiles = gnc::ceil_div(d.rows, RPW);
   int64_t grid = gnc::ceil_div(num_wtiles, RWAVES);
   if (grid > gnc::kNumCU) grid = gnc::kNumCU;  // one persistent workgroup per CU
-  static const int flags = getenv("GNC_MLP_NT") ? atoi(getenv("GNC_MLP_NT")) : 0;  // bit 0: nontemporal streamed rows
   mlp_resident_kernel<HT, OT, NMM, NADD, RESREG>
-      <<<dim3((unsigned)grid), dim3(RNT), smem, stream>>>(d, (int)num_wtiles, total_chunks, flags);
+      <<<dim3((unsigned)grid), dim3(RNT), smem, stream>>>(d, (int)num_wtiles, total_chunks);
   return gnc::check_launch("mlp_resident_kernel");
 }
 
@@ -285,6 +342,8 @@ int gnc_mlp::launch_resident(const gnc_mlp_desc_t& d, int T, bool narrow_out, hi
   for (int s = 0; s < d.num_segments; ++s) {
     const gnc_mlp_segment_t& g = d.seg[s];
     if (g.width > KC || g.ld % 4 != 0 || !al16(g.ptr)) return GNC_OK;
+    // gathers go through a buffer window over the whole table: its size must be stated and below 4 GiB
+    if (g.index && (g.table_rows <= 0 || g.table_rows * (int64_t)g.ld * 4 > 0xffffffffll)) return GNC_OK;
     if (g.mode == GNC_SEG_ADD) {
       ++nadd;
     } else {

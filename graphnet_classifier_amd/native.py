@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 GNC_MAX_SEGMENTS = 4
 GNC_MAX_LINEAR = 8
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 ACTIVATIONS = {  # nn.<Name> accepted by the reference's MLP(activation=...) (models/MLP.py:21)
     "ReLU": 0, "Identity": 1, "Tanh": 2, "Sigmoid": 3, "SiLU": 4, "GELU": 5, "LeakyReLU": 6, "ELU": 7,
@@ -59,7 +59,7 @@ EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 class MlpSegment(Structure):
     _fields_ = [("ptr", c_void_p), ("index", c_void_p), ("width", c_int32), ("ld", c_int32), ("mode", c_int32),
-                ("wcol", c_int32)]
+                ("wcol", c_int32), ("table_rows", c_int64)]
 
 
 class MlpDesc(Structure):
@@ -293,6 +293,7 @@ def make_mlp_desc(segments, weights, biases, ln, activation: str, act_param: flo
         d.seg[s].width = width
         d.seg[s].ld = _ld(table)
         d.seg[s].mode = mode
+        d.seg[s].table_rows = table.size(0) if index is not None else 0
     for l, (w, b) in enumerate(zip(weights, biases)):
         d.weight[l] = w.data_ptr()
         d.ld_weight[l] = _ld(w)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GNC_ABI_VERSION 7
+#define GNC_ABI_VERSION 8
 
 enum {
   GNC_OK = 0,
@@ -139,6 +139,10 @@ typedef struct gnc_mlp_segment {
   int32_t mode;         /* GNC_SEG_MATMUL | GNC_SEG_ADD                    */
   int32_t wcol;         /* MATMUL: first column of weight[0] this segment multiplies (segments may be
                            listed, i.e. staged, in any order; the concat order lives here)          */
+  int64_t table_rows;   /* rows of the table behind ptr = bound of the ids in `index`; 0 = not stated.
+                           With it (and a table below 4 GiB) the fast kernels gather through a
+                           bounds-checked buffer window: an id outside the table reads zeros instead of
+                           faulting.  Without it the flat-address kernels run.  Ignored when index==NULL */
 } gnc_mlp_segment_t;
 
 typedef struct gnc_mlp_desc {

@@ -266,6 +266,22 @@ def test_mlp_additive_segments_equal_concat_form(native, d):
     assert max_abs(y.cpu(), ref) < 1e-5
 
 
+def test_gather_window_id_outside_the_stated_table_reads_zero(native):
+    """gnc_mlp_segment_t.table_rows: the weights-resident kernel gathers through a bounds-checked buffer window,
+    so an id at or beyond the stated table reads zeros.  The table is the first half of a larger allocation, so a
+    kernel that ignored the bound would read real (non-zero) memory, not fault."""
+    rng = np.random.default_rng(77)
+    big = torch.from_numpy(rng.standard_normal((200, 64)).astype(np.float32) + 3.0).to(DEV)
+    table = big[:100]
+    idx = torch.from_numpy(rng.integers(0, 100, size=500).astype(np.int32))
+    idx[::7] = torch.from_numpy(rng.integers(100, 200, size=len(idx[::7])).astype(np.int32))
+    w = torch.from_numpy((rng.standard_normal((64, 64)) / 8).astype(np.float32))
+    b = torch.from_numpy(rng.standard_normal(64).astype(np.float32))
+    y = native.mlp_forward([(table, idx.to(DEV))], [w.to(DEV)], [b.to(DEV)])
+    rows = big.cpu()[idx.long()] * (idx < 100)[:, None]
+    assert max_abs(y.cpu(), rows @ w.t() + b) < 1e-5
+
+
 def test_mlp_rejects_unsupported(native):
     x = torch.zeros(4, 8, device=DEV)
     w = [torch.zeros(300, 8, device=DEV), torch.zeros(4, 300, device=DEV)]

@@ -27,7 +27,10 @@ def lin(o, i):
 
 (w0, b0), (w1, b1), (w2, b2) = lin(d, 3 * d), lin(d, d), lin(d, d)
 ln = (torch.ones(d, device=dev), torch.zeros(d, device=dev), 1e-5)
-for _ in range(iters):
+ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+for it in range(iters):
+    if it == 1:
+        ev0.record()
     if mode == "wsplit":
         ps = native.mlp_forward([(x, None)], [w0[:, :d]], [None])
         pd = native.mlp_forward([(x, None)], [w0[:, d:2 * d]], [None])
@@ -39,5 +42,25 @@ for _ in range(iters):
         e0 = torch.randn(e, 3, device=dev)
         (v0, c0) = lin(d, 3)
         y = native.mlp_forward([(e0, None)], [v0, w1, w2], [c0, b1, b2], ln=ln)
+ev1.record()
 torch.cuda.synchronize()
+if iters > 1:
+    print("ms_per_iter", mode, ev0.elapsed_time(ev1) / (iters - 1))
 print("done", mode, float(y[0, 0]))
+
+# phase probe of the last resident-kernel launch (library built with `make PROBE=1` only)
+import ctypes  # noqa: E402
+
+import numpy as np  # noqa: E402
+
+lib = native.load_library()
+if hasattr(lib, "gnc_phase_probe_read"):
+    buf = np.zeros(2048 * 12, dtype=np.uint64)
+    lib.gnc_phase_probe_read.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    lib.gnc_phase_probe_read(buf.ctypes.data, buf.nbytes)
+    b = buf.reshape(2048, 12).astype(np.float64)
+    tiles = (e + 31) // 32 / 2048
+    names = ["wait+stage", "L0 mfma", "add step", "hidden", "last", "LN+transpose", "epilogue"]
+    print("cycles per tile and wave:", {n: round(v / tiles) for n, v in zip(names, b[:, :7].mean(0))},
+          "total", round(b[:, 8].mean() / tiles))
+    print("shader clock GHz during the kernel:", round(float((b[:, 8] / b[:, 9]).mean()) * 0.1, 3))
