@@ -184,11 +184,15 @@ def main():
     timers = native.KernelTimers()
     native.set_kernel_timers(timers)
     fence()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]  # per-step spread (diagnostic only)
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    marks[0].record()
+    for k in range(a.steps):
         y = step()
+        marks[k + 1].record()
     fence()
     elapsed = time.perf_counter() - t0
+    per_step = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(a.steps))
     native.set_kernel_timers(None)
     ksum = timers.summary()
 
@@ -233,6 +237,7 @@ def main():
                              "bound": "mfma", "achieved": mlp_tflops, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": mlp_tflops / MFMA_F32_PEAK_TFLOPS, "avg_launch_ms": mlp["avg_ms"],
                              "launches": mlp["launches"], "executed_flops_per_launch": mlp["avg_work"]},
+            "step_ms_spread": {"min": per_step[0], "median": per_step[len(per_step) // 2], "max": per_step[-1]},
             "kernel_ms_per_step": {k: v["avg_ms"] * v["launches"] / a.steps for k, v in ksum.items()},
         }
         if world == 1 and not a.no_cpu_baseline and a.mode == "forward":

@@ -190,7 +190,7 @@ __device__ __forceinline__ float add_halves(float x) {
 }
 
 // LayerNorm over the out_dim features of each data row: registers + one cross-half exchange.
-// fp32 MFMA and VALU instructions do NOT overlap on a gfx950 SIMD (tools/mfma_ceiling.hip: one 32x32x2 MFMA
+// fp32 MFMA and VALU instructions do NOT overlap on a gfx950 SIMD (tools/hw_probe.hip: one 32x32x2 MFMA
 // + k VALU = 64 + ~3..5k cycles), so the instruction count here is kernel time: packed fp32 math, no
 // per-feature selects (features >= out_dim hold exact zeros - zero weight rows, zero bias - so they drop out
 // of the sum; their deviations are cleared before the variance when the width is not 32*OT), 1/n as a

@@ -25,7 +25,7 @@
 //   * every load is unconditional: row-ordered tables are read through per-tile buffer windows
 //     (rows past the end read as 0, rows past the end are never stored - the hardware bounds check
 //     does both), gather ids are clamped; there is no exec-masked VMEM in the loop.
-// fp32 MFMA time and VALU time ADD UP on a gfx950 SIMD (tools/mfma_ceiling.hip), so the loop keeps the
+// fp32 MFMA time and VALU time ADD UP on a gfx950 SIMD (tools/hw_probe.hip), so the loop keeps the
 // vector unit out of address arithmetic: windows are built by the scalar unit, per-lane offsets are
 // loop constants, gathered rows cost one v_lshl_add_u64 each.
 // Requirements checked by the launcher (anything else runs the streaming kernel): ReLU,

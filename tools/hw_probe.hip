@@ -1,8 +1,11 @@
-// Measures what the fp32 MFMA pipe of this MI355X sustains (TFLOP/s and implied clock), so that the
-// `roofline_mlp` numbers can be read against an ACHIEVABLE ceiling as well as the 157.3 TFLOP/s spec peak
-// (same role as the copy ceiling next to the 8 TB/s HBM spec).  No memory traffic: every wave runs
-// `iters` x 16 v_mfma_f32_32x32x2_f32 on 4 independent accumulators.
-//   hipcc --offload-arch=gfx950 -O3 tools/mfma_ceiling.hip -o build/mfma_ceiling && build/mfma_ceiling
+// Hardware probes behind the roofline discussion in DESIGN.md (one JSON line per measurement):
+//   mfma        what the fp32 MFMA pipe sustains (TFLOP/s, implied clock) with no memory traffic: every wave
+//               runs `iters` x 16 v_mfma_f32_32x32x2_f32 (1, 2 or 4 accumulators; 1 or 2 waves per SIMD);
+//   coissue     does VALU / LDS work of one wave proceed under the MFMAs of its SIMD mate?
+//   interleave  how many VALU instructions fit in the shadow of a 64-cycle MFMA of the SAME wave?
+//               (answer on gfx950: none - fp32 MFMA time and VALU time add up)
+//   stream_read the read-only HBM ceiling (what K1 is, minus its segment logic), plain and nontemporal.
+//   hipcc --offload-arch=gfx950 -O3 tools/hw_probe.hip -o build/hw_probe && build/hw_probe [iters | r]
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -158,6 +161,55 @@ static void run_coissue(int mfma_iters, int valu_iters, int mode) {
   hipFree(cyc);
 }
 
+// Pure streaming read (what K1 is, minus its segment logic): every lane sums 16-B loads, U in flight, grid-
+// stride over `n4` float4s.  Gives the read-only HBM ceiling next to the 8 TB/s spec and the copy ceiling.
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void stream_read(const f32x4* __restrict__ p, size_t n4, float* out) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  for (; i + (U - 1) * stride < n4; i += U * stride) {
+    f32x4 r[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) r[u] = NT ? __builtin_nontemporal_load(p + i + u * stride) : p[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < U; ++u) a += r[u];
+  }
+  for (; i < n4; i += stride) a += p[i];
+  if (a.x + a.y + a.z + a.w == 123.456f) out[0] = a.x;
+}
+
+template <int U, bool NT>
+static void run_read(size_t bytes, int blocks_per_cu) {
+  f32x4* p;
+  float* out;
+  hipMalloc(&p, bytes);
+  hipMalloc(&out, 4);
+  hipMemset(p, 0, bytes);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  const size_t n4 = bytes / 16;
+  stream_read<U, NT><<<256 * blocks_per_cu, 256>>>(p, n4, out);
+  hipDeviceSynchronize();
+  float sum = 0.f;
+  const int reps = 10;
+  for (int r = 0; r < reps; ++r) {
+    hipEventRecord(e0);
+    stream_read<U, NT><<<256 * blocks_per_cu, 256>>>(p, n4, out);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    sum += ms;
+  }
+  printf("{\"probe\": \"stream_read\", \"GB\": %.2f, \"loads_in_flight\": %d, \"nontemporal\": %s, \"blocks_per_cu\": %d, "
+         "\"ms_avg\": %.3f, \"TBps\": %.2f}\n", bytes / 1e9, U, NT ? "true" : "false", blocks_per_cu, sum / reps,
+         bytes / (sum / reps * 1e-3) / 1e12);
+  hipFree(p);
+  hipFree(out);
+}
+
 template <int NACC>
 static void run(int waves_per_cu, int iters) {
   float* out;
@@ -190,6 +242,16 @@ static void run(int waves_per_cu, int iters) {
 }
 
 int main(int argc, char** argv) {
+  if (argc > 1 && argv[1][0] == 'r') {  // `hw_probe r`: only the HBM read probe
+    const size_t bytes = 2560000000ull;  // K1's message stream at c3 size
+    run_read<4, false>(bytes, 8);
+    run_read<4, true>(bytes, 8);
+    run_read<8, true>(bytes, 8);
+    run_read<8, true>(bytes, 4);
+    run_read<4, true>(bytes, 16);
+    run_read<8, false>(bytes, 8);
+    return 0;
+  }
   const int iters = argc > 1 ? atoi(argv[1]) : 100000;  // ~0.1 s of MFMA per launch
   run<4>(4, iters);
   run<4>(8, iters);
@@ -215,5 +277,10 @@ int main(int argc, char** argv) {
   run_interleave<8>(20000, 8);
   run_interleave<12>(20000, 8);
   run_interleave<16>(20000, 8);
+  const size_t bytes = 2560000000ull;
+  run_read<4, false>(bytes, 8);
+  run_read<4, true>(bytes, 8);
+  run_read<8, true>(bytes, 8);
+  run_read<4, true>(bytes, 16);
   return 0;
 }
