@@ -159,15 +159,29 @@ __global__ __launch_bounds__(BNT) void mlp_backward_data_kernel(const gnc_mlp_de
       pre[p] = *reinterpret_cast<const f32x4*>(base + (int64_t)tr * ld + col);
     }
   };
+  // row-ordered table: one buffer window per tile, no address arithmetic on the vector unit, rows past the end read 0
+  auto load_rows_seq = [&](f32x4 (&pre)[NP], const float* base, int ld, int row0) {
+    const int col = c4 * 4 < ld ? c4 * 4 : 0;
+    load_tile_rows(pre, base, ld, row0, rows, (uint32_t)(rs * ld + col) * 4u);
+  };
+  auto load_seg = [&](f32x4 (&pre)[NP], const SegView& sg, int wt) {
+    if (sg.index) load_rows(pre, sg.ptr, sg.ld, load_idx(wt, sg));
+    else load_rows_seq(pre, sg.ptr, sg.ld, wt * RPW);
+  };
   auto stage = [&](const f32x4 (&pre)[NP], int width) {
     compiler_lds_barrier();
     const int c = c4 * 4;
+    if (width >= KC) {
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      f32x4 v = pre[p];
-      v.x = c + 0 < width ? v.x : 0.f; v.y = c + 1 < width ? v.y : 0.f;
-      v.z = c + 2 < width ? v.z : 0.f; v.w = c + 3 < width ? v.w : 0.f;
-      *reinterpret_cast<f32x4*>(abuf + (p * 4 + rs) * LDSW + c) = v;
+      for (int p = 0; p < NP; ++p) *reinterpret_cast<f32x4*>(abuf + (p * 4 + rs) * LDSW + c) = pre[p];
+    } else {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        f32x4 v = pre[p];
+        v.x = c + 0 < width ? v.x : 0.f; v.y = c + 1 < width ? v.y : 0.f;
+        v.z = c + 2 < width ? v.z : 0.f; v.w = c + 3 < width ? v.w : 0.f;
+        *reinterpret_cast<f32x4*>(abuf + (p * 4 + rs) * LDSW + c) = v;
+      }
     }
     compiler_lds_barrier();
   };
@@ -176,14 +190,7 @@ __global__ __launch_bounds__(BNT) void mlp_backward_data_kernel(const gnc_mlp_de
     compiler_lds_barrier();
     tiles_to_lds<HT>(acc, abuf, i, h);
     compiler_lds_barrier();
-    const int col = c4 * 4;
-    const bool vec = (width % 4 == 0) && (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0);
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      const int r = row0 + p * 4 + rs;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(abuf + (p * 4 + rs) * LDSW + col);
-      store_row_piece(dst + (int64_t)(r < rows ? r : rows - 1) * ld, col, v, r < rows && col < width, width, vec);
-    }
+    store_staged_rows(abuf, dst, ld, width, row0, rows, c4, rs);
     compiler_lds_barrier();
   };
 
@@ -196,21 +203,19 @@ __global__ __launch_bounds__(BNT) void mlp_backward_data_kernel(const gnc_mlp_de
     f32x4 gpre[NP];  // grad_out rows of this tile: requested early, consumed after the forward recompute
     {
       f32x4 pre[NP], pre2[NP], pre3[NP];
-      load_rows(pre, sv[0].ptr, sv[0].ld, load_idx(wt, sv[0]));
+      load_seg(pre, sv[0], wt);
 #pragma unroll
       for (int s = 0; s < NMM; ++s) {
         stage(pre, sv[s].width);
         // request the next step's rows (and, at the last MATMUL step, the additive gathers and grad_out) before the MFMAs
         if (s + 1 < NMM) {
-          load_rows(pre, sv[s + 1 < NMM ? s + 1 : 0].ptr, sv[s + 1 < NMM ? s + 1 : 0].ld, load_idx(wt, sv[s + 1 < NMM ? s + 1 : 0]));
+          load_seg(pre, sv[s + 1 < NMM ? s + 1 : 0], wt);
         } else {
           if constexpr (NADD > 0) {
-            load_rows(pre2, sv[NMM].ptr, sv[NMM].ld, load_idx(wt, sv[NMM]));
-            load_rows(pre3, sv[NMM + 1].ptr, sv[NMM + 1].ld, load_idx(wt, sv[NMM + 1]));
+            load_seg(pre2, sv[NMM], wt);
+            load_seg(pre3, sv[NMM + 1], wt);
           }
-          int r = row0 + (lane & 31);
-          r = r < rows ? r : rows - 1;
-          load_rows(gpre, b.grad_out, b.ld_grad_out, r);
+          load_rows_seq(gpre, b.grad_out, b.ld_grad_out, row0);
         }
         mma_chunk_from_lds<HT>(hid, abuf, wres + s * CH, (sv[s].width + 7) >> 3, i, h);
       }
@@ -248,55 +253,8 @@ __global__ __launch_bounds__(BNT) void mlp_backward_data_kernel(const gnc_mlp_de
       f32x16 y[HT];
       init_bias<HT>(y, pbuf + (L - 1) * PSTRIDE, h);
       mma_chunk_from_regs<HT, HT>(y, hid, wres + (NMM + L - 2) * CH, 0, d.in_dim[L - 1], i, h);
-      // statistics of the row (lane): y -> normalised y_hat
-      float s = 0.f;
-#pragma unroll
-      for (int t = 0; t < HT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s += (feat_of(t, r, h) < out_dim) ? y[t][r] : 0.f;
-      s += __shfl_xor(s, 32, 64);
-      const float mean = s / (float)out_dim;
-      float v = 0.f;
-#pragma unroll
-      for (int t = 0; t < HT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float dl = y[t][r] - mean;
-          v += (feat_of(t, r, h) < out_dim) ? dl * dl : 0.f;
-        }
-      v += __shfl_xor(v, 32, 64);
-      const float rstd = 1.f / sqrtf(v / (float)out_dim + d.ln_eps);
-      const float* pg = pbuf + L * PSTRIDE;
-      float m1 = 0.f, m2 = 0.f;
-#pragma unroll
-      for (int t = 0; t < HT; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 gm = *reinterpret_cast<const f32x4*>(pg + 32 * t + 8 * q + 4 * h);
-          const float gmv[4] = {gm.x, gm.y, gm.z, gm.w};
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int r = 4 * q + k;
-            const bool ok = feat_of(t, r, h) < out_dim;
-            const float yh = ok ? (y[t][r] - mean) * rstd : 0.f;
-            const float gv = ok ? g[t][r] : 0.f;
-            const float gg = gv * gmv[k];  // gamma is zero-padded
-            m1 += gg;
-            m2 += gg * yh;
-            y[t][r] = yh;
-            g[t][r] = gg;
-          }
-        }
+      layer_norm_backward_tiles<HT>(y, g, pbuf + L * PSTRIDE, out_dim, d.ln_eps, h);
       emit(y, b.yhat, out_dim, out_dim, row0);  // normalised pre-affine output: d gamma = colsum(grad_out * yhat)
-      m1 += __shfl_xor(m1, 32, 64);
-      m2 += __shfl_xor(m2, 32, 64);
-      m1 /= (float)out_dim;
-      m2 /= (float)out_dim;
-#pragma unroll
-      for (int t = 0; t < HT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          g[t][r] = (feat_of(t, r, h) < out_dim) ? rstd * (g[t][r] - m1 - y[t][r] * m2) : 0.f;
     } else {
 #pragma unroll
       for (int t = 0; t < HT; ++t)
@@ -328,19 +286,7 @@ __global__ __launch_bounds__(BNT) void mlp_backward_data_kernel(const gnc_mlp_de
           compiler_lds_barrier();
           tiles_to_lds<HT>(dxs, abuf, i, h);
           compiler_lds_barrier();
-          const int col = c4 * 4;
-          float* dst = b.dx + d.seg[s].wcol;
-          const int width = sv[s].width;
-          const bool vec = (width % 4 == 0) && (b.ld_dx % 4 == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0);
-          const int gc = col < b.ld_grad_out ? col : 0;
-#pragma unroll
-          for (int p = 0; p < NP; ++p) {
-            const int r = row0 + p * 4 + rs;
-            const int rc = r < rows ? r : rows - 1;
-            f32x4 v = *reinterpret_cast<const f32x4*>(abuf + (p * 4 + rs) * LDSW + col);
-            v += *reinterpret_cast<const f32x4*>(b.grad_out + (int64_t)rc * b.ld_grad_out + gc);
-            store_row_piece(dst + (int64_t)rc * b.ld_dx, col, v, r < rows && col < width, width, vec);
-          }
+          store_staged_rows(abuf, b.dx + d.seg[s].wcol, b.ld_dx, sv[s].width, row0, rows, c4, rs, b.grad_out, b.ld_grad_out);
           compiler_lds_barrier();
         } else {
           emit(dxs, b.dx + d.seg[s].wcol, b.ld_dx, sv[s].width, row0);
@@ -465,14 +411,7 @@ __global__ __launch_bounds__(256) void mlp_backward_stream_kernel(const gnc_mlp_
   // 64 columns [64*cc, +64) of `acc` -> rows of dst (columns < width)
   auto emit_chunk = [&](float* dst, int ld, int width, int row0, int cc) {
     compiler_lds_barrier();
-    const int col = cc * KC + c4 * 4;
-    const bool vec = (width % 4 == 0) && (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0);
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      const int r = row0 + p * 4 + rs;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(abuf + (p * 4 + rs) * LDSW + c4 * 4);
-      store_row_piece(dst + (int64_t)(r < rows ? r : rows - 1) * ld, col, v, r < rows && col < width, width, vec);
-    }
+    store_staged_rows(abuf, dst + cc * KC, ld, width - cc * KC < KC ? width - cc * KC : KC, row0, rows, c4, rs);
     compiler_lds_barrier();
   };
   auto emit = [&](const f32x16 (&acc)[HT], float* dst, int ld, int width, int row0) {
@@ -629,53 +568,8 @@ __global__ __launch_bounds__(256) void mlp_backward_stream_kernel(const gnc_mlp_
           publish_next_chunk();
         }
       }
-      float s = 0.f;
-#pragma unroll
-      for (int t = 0; t < HT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s += (feat_of(t, r, h) < out_dim) ? y[t][r] : 0.f;
-      s += __shfl_xor(s, 32, 64);
-      const float mean = s / (float)out_dim;
-      float v = 0.f;
-#pragma unroll
-      for (int t = 0; t < HT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float dl = y[t][r] - mean;
-          v += (feat_of(t, r, h) < out_dim) ? dl * dl : 0.f;
-        }
-      v += __shfl_xor(v, 32, 64);
-      const float rstd = 1.f / sqrtf(v / (float)out_dim + d.ln_eps);
-      const float* pg = pbuf + L * PSTRIDE;
-      float m1 = 0.f, m2 = 0.f;
-#pragma unroll
-      for (int t = 0; t < HT; ++t)
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq) {
-          const f32x4 gm = *reinterpret_cast<const f32x4*>(pg + 32 * t + 8 * qq + 4 * h);
-          const float gmv[4] = {gm.x, gm.y, gm.z, gm.w};
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int r = 4 * qq + k;
-            const bool ok = feat_of(t, r, h) < out_dim;
-            const float yh = ok ? (y[t][r] - mean) * rstd : 0.f;
-            const float gg = (ok ? g[t][r] : 0.f) * gmv[k];
-            m1 += gg;
-            m2 += gg * yh;
-            y[t][r] = yh;
-            g[t][r] = gg;
-          }
-        }
+      layer_norm_backward_tiles<HT>(y, g, pbuf + L * PSTRIDE, out_dim, d.ln_eps, h);
       emit(y, b.yhat, out_dim, out_dim, row0);
-      m1 += __shfl_xor(m1, 32, 64);
-      m2 += __shfl_xor(m2, 32, 64);
-      m1 /= (float)out_dim;
-      m2 /= (float)out_dim;
-#pragma unroll
-      for (int t = 0; t < HT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          g[t][r] = (feat_of(t, r, h) < out_dim) ? rstd * (g[t][r] - m1 - y[t][r] * m2) : 0.f;
     } else {
 #pragma unroll
       for (int t = 0; t < HT; ++t)
@@ -715,16 +609,8 @@ __global__ __launch_bounds__(256) void mlp_backward_stream_kernel(const gnc_mlp_
         // columns c0 .. c0+63 of segment s -> dx[:, wcol_s + c0 ...]
         {
           compiler_lds_barrier();
-          float* dst = b.dx + d.seg[s].wcol + c0;
-          const int width = d.seg[s].width - c0 < KC ? d.seg[s].width - c0 : KC;
-          const int col = c4 * 4;
-          const bool vec = (width % 4 == 0) && (b.ld_dx % 4 == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0);
-#pragma unroll
-          for (int p = 0; p < NP; ++p) {
-            const int r = row0 + p * 4 + rs;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(abuf + (p * 4 + rs) * LDSW + col);
-            store_row_piece(dst + (int64_t)(r < rows ? r : rows - 1) * b.ld_dx, col, v, r < rows && col < width, width, vec);
-          }
+          store_staged_rows(abuf, b.dx + d.seg[s].wcol + c0, b.ld_dx, d.seg[s].width - c0 < KC ? d.seg[s].width - c0 : KC, row0,
+                            rows, c4, rs);
           compiler_lds_barrier();
         }
       }
@@ -770,6 +656,10 @@ __global__ __launch_bounds__(256) void xty_kernel(const float* __restrict__ A, i
 
   auto load_tile = [&](f32x4 (&pre)[NP], const float* base, int64_t ld, int width, bool vec, int tile) {
     const int col = c4 * 4;
+    if (vec && width == KC) {  // full-width operand: one buffer window per tile, rows past the end read as 0
+      load_tile_rows<true>(pre, base, (int)ld, (int64_t)tile * RPW, rows, (uint32_t)(rs * (int)ld + col) * 4u);
+      return;
+    }
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       const int r = tile * RPW + p * 4 + rs;
@@ -807,6 +697,7 @@ __global__ __launch_bounds__(256) void xty_kernel(const float* __restrict__ A, i
     const int nt = tile + total_waves;  // next tile's rows fly while this one is multiplied (clamped: always legal)
     load_tile(pa, A, lda, M, avec, nt < num_tiles ? nt : num_tiles - 1);
     load_tile(pb, B, ldb, K, bvec, nt < num_tiles ? nt : num_tiles - 1);
+    // (the windowed path would also be legal past the end; clamping keeps both paths on one schedule)
 #pragma unroll 4
     for (int s = 0; s < RPW / 2; ++s) {
       float av[TM], bv[TK];

@@ -250,6 +250,90 @@ __device__ __forceinline__ void layer_norm_tiles(f32x16 (&o)[OT], const float* p
     }
 }
 
+// LayerNorm backward on the accumulator layout, same instruction diet as layer_norm_tiles:
+//   in : y = pre-LayerNorm output of the row (features >= out_dim exact zeros), g = grad wrt the LayerNorm output
+//   out: y = y_hat (normalised, pre-affine; zeros beyond out_dim), g = grad wrt the pre-LayerNorm output
+// (d gamma = colsum(grad_out * y_hat), d beta = colsum(grad_out) are formed elsewhere from y_hat.)
+template <int HT>
+__device__ __forceinline__ void layer_norm_backward_tiles(f32x16 (&y)[HT], f32x16 (&g)[HT], const float* pg, int out_dim,
+                                                          float eps, int h) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const float inv_n = 1.f / (float)out_dim;
+  const bool padded = out_dim != HT * 32;  // wave-uniform, rare
+  f32x2 sa = {0.f, 0.f}, sb = {0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < HT; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      sa += f32x2{y[t][4 * q + 0], y[t][4 * q + 1]};
+      sb += f32x2{y[t][4 * q + 2], y[t][4 * q + 3]};
+    }
+  const float mean = add_halves((sa.x + sa.y) + (sb.x + sb.y)) * inv_n;
+  const f32x2 m2v = {mean, mean};
+#pragma unroll
+  for (int t = 0; t < HT; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x2 da = f32x2{y[t][4 * q + 0], y[t][4 * q + 1]} - m2v;
+      const f32x2 db = f32x2{y[t][4 * q + 2], y[t][4 * q + 3]} - m2v;
+      y[t][4 * q + 0] = da.x; y[t][4 * q + 1] = da.y; y[t][4 * q + 2] = db.x; y[t][4 * q + 3] = db.y;
+    }
+  if (padded) {
+#pragma unroll
+    for (int t = 0; t < HT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const bool ok = feat_of(t, r, h) < out_dim;
+        y[t][r] = ok ? y[t][r] : 0.f;
+        g[t][r] = ok ? g[t][r] : 0.f;
+      }
+  }
+  f32x2 va = {0.f, 0.f}, vb = {0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < HT; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x2 da = {y[t][4 * q + 0], y[t][4 * q + 1]}, db = {y[t][4 * q + 2], y[t][4 * q + 3]};
+      va = __builtin_elementwise_fma(da, da, va);
+      vb = __builtin_elementwise_fma(db, db, vb);
+    }
+  const float rstd = __frsqrt_rn(add_halves((va.x + va.y) + (vb.x + vb.y)) * inv_n + eps);
+  const f32x2 r2 = {rstd, rstd};
+  f32x2 m1a = {0.f, 0.f}, m1b = {0.f, 0.f}, m2a = {0.f, 0.f}, m2b = {0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < HT; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(pg + 32 * t + 8 * q + 4 * h);  // gamma, zero padded
+      const f32x2 ya = f32x2{y[t][4 * q + 0], y[t][4 * q + 1]} * r2, yb = f32x2{y[t][4 * q + 2], y[t][4 * q + 3]} * r2;
+      const f32x2 ga = f32x2{g[t][4 * q + 0], g[t][4 * q + 1]} * f32x2{gm.x, gm.y};
+      const f32x2 gb = f32x2{g[t][4 * q + 2], g[t][4 * q + 3]} * f32x2{gm.z, gm.w};
+      m1a += ga; m1b += gb;
+      m2a = __builtin_elementwise_fma(ga, ya, m2a);
+      m2b = __builtin_elementwise_fma(gb, yb, m2b);
+      y[t][4 * q + 0] = ya.x; y[t][4 * q + 1] = ya.y; y[t][4 * q + 2] = yb.x; y[t][4 * q + 3] = yb.y;
+      g[t][4 * q + 0] = ga.x; g[t][4 * q + 1] = ga.y; g[t][4 * q + 2] = gb.x; g[t][4 * q + 3] = gb.y;
+    }
+  const float m1 = add_halves((m1a.x + m1a.y) + (m1b.x + m1b.y)) * inv_n;
+  const float m2 = add_halves((m2a.x + m2a.y) + (m2b.x + m2b.y)) * inv_n;
+  const f32x2 nm1 = {-m1, -m1}, nm2 = {-m2, -m2};
+#pragma unroll
+  for (int t = 0; t < HT; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      // rstd * (g - m1 - y_hat * m2)
+      const f32x2 ua = __builtin_elementwise_fma(f32x2{y[t][4 * q + 0], y[t][4 * q + 1]}, nm2, f32x2{g[t][4 * q + 0], g[t][4 * q + 1]} + nm1) * r2;
+      const f32x2 ub = __builtin_elementwise_fma(f32x2{y[t][4 * q + 2], y[t][4 * q + 3]}, nm2, f32x2{g[t][4 * q + 2], g[t][4 * q + 3]} + nm1) * r2;
+      g[t][4 * q + 0] = ua.x; g[t][4 * q + 1] = ua.y; g[t][4 * q + 2] = ub.x; g[t][4 * q + 3] = ub.y;
+    }
+  if (padded) {
+#pragma unroll
+    for (int t = 0; t < HT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) g[t][r] = (feat_of(t, r, h) < out_dim) ? g[t][r] : 0.f;
+  }
+}
+
 // Epilogue: transpose the output tiles through the wave's private LDS tile, add the residual
 // and store whole rows (16 lanes x 16 B per row).
 // true when the residual rows are exactly what the last staging step left in the wave's tile
@@ -374,14 +458,118 @@ __device__ __forceinline__ f32x4 window_load(__amdgpu_buffer_rsrc_t w, uint32_t 
   return __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(w, byte_off, 0, 0));
 }
 
+// same, for rows that are read exactly once (nontemporal: keeps the stream out of L2 / MALL)
+__device__ __forceinline__ f32x4 window_load_stream(__amdgpu_buffer_rsrc_t w, uint32_t byte_off) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  return __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(w, byte_off, 0, 2 /* nt */));
+}
+
 // 16-B store into a window, issued behind the compiler's back (same reason as hidden_store_b128)
 __device__ __forceinline__ void hidden_window_store(f32x4 v, uint32_t byte_off, __amdgpu_buffer_rsrc_t w) {
+  // s_nop 4 first: the descriptor SGPRs may just have been restored by v_readlane (SGPR spill), and a VALU
+  // write of an SGPR needs 5 wait states before a VMEM instruction reads it - the hazard recognizer does not
+  // look inside inline asm.  s_nop 1 after: the store data registers may be overwritten right away.
   asm volatile(
+      "s_nop 4\n\t"
       "buffer_store_dwordx4 %0, %1, %2, 0 offen\n\t"
       "s_nop 1"
       :
       : "v"(v), "v"(byte_off), "s"(w)
       : "memory");
+}
+
+// A tile's eight 4-row pieces through windows.  Full tiles: ONE window, the piece offset rides in the
+// instruction's SGPR offset (1 SALU per piece, no VGPR, but that field is not bounds-checked).  The last tile
+// and anything beyond the table: one window per piece, so the bounds check sees the row.
+template <bool STREAM = false>
+__device__ __forceinline__ void load_tile_rows(f32x4 (&pre)[8], const float* base, int ld, int64_t row0, int64_t rows,
+                                               uint32_t lane_off) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  if (row0 + 32 <= rows) {
+    const __amdgpu_buffer_rsrc_t w = row_window(base, row0, rows, ld);
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+      pre[p] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(w, lane_off, p * 16 * ld, STREAM ? 2 : 0));
+  } else {
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+      pre[p] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(row_window(base, row0 + 4 * p, rows, ld),
+                                                                                     lane_off, 0, STREAM ? 2 : 0));
+  }
+}
+
+__device__ __forceinline__ void hidden_window_store_s(f32x4 v, uint32_t byte_off, __amdgpu_buffer_rsrc_t w, uint32_t soff) {
+  asm volatile(
+      "s_nop 4\n\t"  // VALU-written SGPR (v_readlane restore) -> VMEM read: 5 wait states, see hidden_window_store
+      "buffer_store_dwordx4 %0, %1, %2, %3 offen\n\t"
+      "s_nop 1"
+      :
+      : "v"(v), "v"(byte_off), "s"(w), "s"(soff)
+      : "memory");
+}
+
+// one output row group (declared below)
+__device__ __forceinline__ void store_row_piece(float* rowp, int col, f32x4 v, bool row_ok, int out_dim, bool vec_out);
+
+// The wave's staged [32][64] LDS tile -> columns [0, width) of rows row0.. of dst ([rows, ld]; dst may point at a
+// column offset inside a wider tensor), optionally + the same rows of `add` ([rows, ld_add], first 64 columns).
+// Vector case (width % 4 == 0, ld % 4 == 0, 16-B aligned): windows as in load_tile_rows, no VALU per store,
+// rows past the end dropped by the bounds check; otherwise the masked scalar path.
+__device__ __forceinline__ void store_staged_rows(const float* abuf, float* dst, int ld, int width, int row0, int rows,
+                                                  int c4, int rs, const float* add = nullptr, int ld_add = 0) {
+  const int col = c4 * 4;
+  const bool vec = (width % 4 == 0) && (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0);
+  const float* src = abuf + rs * LDSW + col;
+  if (add) {  // rows this tile has read before: L2 hits; rows past the end read as 0
+    f32x4 v[NP];
+    const uint32_t aoff = (uint32_t)(rs * ld_add + (col < ld_add ? col : 0)) * 4u;
+    load_tile_rows(v, add, ld_add, row0, rows, aoff);
+    if (vec) {
+      const uint32_t off = (uint32_t)(rs * ld + col) * 4u;
+      if (col < width) {
+        if (row0 + RPW <= rows) {
+          const __amdgpu_buffer_rsrc_t w = row_window(dst, row0, rows, ld);
+#pragma unroll
+          for (int p = 0; p < NP; ++p)
+            hidden_window_store_s(v[p] + *reinterpret_cast<const f32x4*>(src + p * 4 * LDSW), off, w, (uint32_t)(p * 16 * ld));
+        } else {
+#pragma unroll
+          for (int p = 0; p < NP; ++p)
+            hidden_window_store(v[p] + *reinterpret_cast<const f32x4*>(src + p * 4 * LDSW), off, row_window(dst, row0 + 4 * p, rows, ld));
+        }
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int r = row0 + p * 4 + rs;
+        store_row_piece(dst + (int64_t)(r < rows ? r : rows - 1) * ld, col, v[p] + *reinterpret_cast<const f32x4*>(src + p * 4 * LDSW),
+                        r < rows && col < width, width, false);
+      }
+    }
+    return;
+  }
+  if (vec) {  // one piece at a time: 4 live registers, the asm stores keep the order
+    const uint32_t off = (uint32_t)(rs * ld + col) * 4u;
+    if (col < width) {
+      if (row0 + RPW <= rows) {
+        const __amdgpu_buffer_rsrc_t w = row_window(dst, row0, rows, ld);
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+          hidden_window_store_s(*reinterpret_cast<const f32x4*>(src + p * 4 * LDSW), off, w, (uint32_t)(p * 16 * ld));
+      } else {
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+          hidden_window_store(*reinterpret_cast<const f32x4*>(src + p * 4 * LDSW), off, row_window(dst, row0 + 4 * p, rows, ld));
+      }
+    }
+  } else {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int r = row0 + p * 4 + rs;
+      store_row_piece(dst + (int64_t)(r < rows ? r : rows - 1) * ld, col, *reinterpret_cast<const f32x4*>(src + p * 4 * LDSW),
+                      r < rows && col < width, width, false);
+    }
+  }
 }
 
 // one output row group: 16-B store when the row layout allows it, else up to four masked scalar stores

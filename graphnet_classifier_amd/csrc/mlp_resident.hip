@@ -130,16 +130,14 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
     return (uint32_t)s.index[r];
   };
   // the step's rows: lane (rs, c4) gets 16 B of row p*4+rs for p = 0..7; no predication anywhere.
-  //   row-ordered table: one window per tile (SALU), per-lane byte offsets are loop constants, rows past
-  //                      the end read as 0;
+  //   row-ordered table: one window per tile, piece offsets in the SGPR offset field, ONE loop-constant
+  //                      per-lane byte offset; the last tile moves the window per piece so that rows past
+  //                      the end read as 0 (load_tile_rows);
   //   gathered table:    the row's offset arrives by ds_bpermute, one v_lshl_add_u64 per access.
   auto load_rows = [&](f32x4 (&pre)[NP], const SegView& s, int wt, uint32_t off) {
     const int col = c4 * 4 < s.ld ? c4 * 4 : 0;
     if (s.index == nullptr) {
-      const __amdgpu_buffer_rsrc_t w = row_window(s.ptr, (int64_t)wt * RPW, rows, s.ld);
-      const uint32_t lane_off = (uint32_t)(rs * s.ld + col) * 4u;
-#pragma unroll
-      for (int p = 0; p < NP; ++p) pre[p] = window_load(w, lane_off + (uint32_t)(p * 16) * (uint32_t)s.ld);
+      load_tile_rows(pre, s.ptr, s.ld, (int64_t)wt * RPW, rows, (uint32_t)(rs * s.ld + col) * 4u);
     } else {
       const __amdgpu_buffer_rsrc_t w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s.ptr), 0, (int)s.bytes, 0x00020000);
       const uint32_t row_bytes = off * (uint32_t)(s.ld * 4);  // byte offset of this lane's tile row, once per tile
@@ -280,15 +278,21 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
 #pragma unroll
       for (int p = 0; p < NP; ++p) outv[p] = *reinterpret_cast<const f32x4*>(abuf + (p * 4 + rs) * LDSW + col_out);
       if (!RESREG && d.residual) {  // rows this tile has just read: L2 hits; rows past the end read as 0
-        const __amdgpu_buffer_rsrc_t rw = row_window(d.residual, row0, rows, d.ld_residual);
+        f32x4 rv[NP];
+        load_tile_rows(rv, d.residual, d.ld_residual, row0, rows, res_lane_off);
 #pragma unroll
-        for (int p = 0; p < NP; ++p) outv[p] += window_load(rw, res_lane_off + (uint32_t)(p * 16) * (uint32_t)d.ld_residual);
+        for (int p = 0; p < NP; ++p) outv[p] += rv[p];
       }
       if (vec_out) {  // rows past the end are dropped by the window's bounds check
-        const __amdgpu_buffer_rsrc_t ow = row_window(d.out, row0, rows, d.ld_out);
         if (col_out < out_dim) {
+          if (row0 + RPW <= rows) {
+            const __amdgpu_buffer_rsrc_t ow = row_window(d.out, row0, rows, d.ld_out);
 #pragma unroll
-          for (int p = 0; p < NP; ++p) hidden_window_store(outv[p], out_lane_off + (uint32_t)(p * 16) * (uint32_t)d.ld_out, ow);
+            for (int p = 0; p < NP; ++p) hidden_window_store_s(outv[p], out_lane_off, ow, (uint32_t)(p * 16 * d.ld_out));
+          } else {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) hidden_window_store(outv[p], out_lane_off, row_window(d.out, row0 + 4 * p, rows, d.ld_out));
+          }
         }
       } else {
 #pragma unroll
