@@ -522,7 +522,7 @@ __device__ __forceinline__ void store_staged_rows(const float* abuf, float* dst,
   const float* src = abuf + rs * LDSW + col;
   if (add) {  // rows this tile has read before: L2 hits; rows past the end read as 0
     f32x4 v[NP];
-    const uint32_t aoff = (uint32_t)(rs * ld_add + (col < ld_add ? col : 0)) * 4u;
+    const uint32_t aoff = (uint32_t)(rs * ld_add + (col < width ? col : 0)) * 4u;  // lanes beyond `width` are not stored
     load_tile_rows(v, add, ld_add, row0, rows, aoff);
     if (vec) {
       const uint32_t off = (uint32_t)(rs * ld + col) * 4u;

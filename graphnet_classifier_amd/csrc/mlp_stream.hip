@@ -79,8 +79,20 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_stream_kernel(const gnc_mlp_de
     const int ldw = ldw_of(d, layer);
     const int nrows = d.out_dim[layer];
     const int klimit = pl.wc[q].klimit;
-    const int col = pl.wc[q].kbase + wc4 * 4;
-    const int colc = col < klimit ? col : pl.wc[q].kbase;
+    const int kbase = pl.wc[q].kbase;
+    if (kbase + KC <= klimit && ldw % 4 == 0 && (reinterpret_cast<uintptr_t>(W) & 15u) == 0 &&
+        (int64_t)nrows * ldw * 4 <= 0xffffffffll) {
+      // full 64-column chunk of an aligned matrix: a window over the matrix, rows >= nrows read as 0 through
+      // the bounds check, no masks, one 32-bit add per load
+      const __amdgpu_buffer_rsrc_t w =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, nrows * ldw * 4, 0x00020000);
+      const uint32_t off0 = (uint32_t)(wr0 * ldw + kbase + wc4 * 4) * 4u;
+#pragma unroll
+      for (int p = 0; p < NW; ++p) wr[p] = window_load(w, off0 + (uint32_t)(p * RPP * 4) * (uint32_t)ldw);
+      return;
+    }
+    const int col = kbase + wc4 * 4;
+    const int colc = col < klimit ? col : kbase;
 #pragma unroll
     for (int p = 0; p < NW; ++p) {
       const int n = p * RPP + wr0;
@@ -106,25 +118,35 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_stream_kernel(const gnc_mlp_de
     const int32_t* ip = d.seg[s].index;
     return ip ? ip[r] : r;
   };
-  auto load_rows = [&](f32x4 (&pre)[NP], int s, int c0, int idxv) {
+  // `tile_of` = the tile these rows belong to (row-ordered segments are read through a window at its first row)
+  auto load_rows = [&](f32x4 (&pre)[NP], int s, int c0, int idxv, int tile_of) {
     const float* base = d.seg[s].ptr;
     const int ld = d.seg[s].ld;
     const int col = c0 + c4 * 4 < ld ? c0 + c4 * 4 : 0;
+    if (d.seg[s].index == nullptr) {
+      load_tile_rows(pre, base, ld, ((int64_t)tile_of * WAVES + wave) * RPW, rows, (uint32_t)(rs * ld + col) * 4u);
+    } else {
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      const int tr = __shfl(idxv, p * 4 + rs, 64);
-      pre[p] = *reinterpret_cast<const f32x4*>(base + (int64_t)tr * ld + col);
+      for (int p = 0; p < NP; ++p) {
+        const int tr = __shfl(idxv, p * 4 + rs, 64);
+        pre[p] = *reinterpret_cast<const f32x4*>(base + (int64_t)tr * ld + col);
+      }
     }
   };
   auto stage = [&](const f32x4 (&pre)[NP], int c0, int width) {
     compiler_lds_barrier();
     const int c = c0 + c4 * 4;
+    if (c0 + KC <= width) {  // full chunk: nothing to mask
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      f32x4 v = pre[p];
-      v.x = c + 0 < width ? v.x : 0.f; v.y = c + 1 < width ? v.y : 0.f;
-      v.z = c + 2 < width ? v.z : 0.f; v.w = c + 3 < width ? v.w : 0.f;
-      *reinterpret_cast<f32x4*>(abuf + (p * 4 + rs) * LDSW + c4 * 4) = v;
+      for (int p = 0; p < NP; ++p) *reinterpret_cast<f32x4*>(abuf + (p * 4 + rs) * LDSW + c4 * 4) = pre[p];
+    } else {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        f32x4 v = pre[p];
+        v.x = c + 0 < width ? v.x : 0.f; v.y = c + 1 < width ? v.y : 0.f;
+        v.z = c + 2 < width ? v.z : 0.f; v.w = c + 3 < width ? v.w : 0.f;
+        *reinterpret_cast<f32x4*>(abuf + (p * 4 + rs) * LDSW + c4 * 4) = v;
+      }
     }
     compiler_lds_barrier();
   };
@@ -145,12 +167,12 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_stream_kernel(const gnc_mlp_de
     int idv = 0;
 #pragma unroll
     for (int s = 0; s < GNC_MAX_SEGMENTS; ++s) idv = s == s0 ? ids[s] : idv;
-    load_rows(cur, s0, pl.step[0].c0, idv);
+    load_rows(cur, s0, pl.step[0].c0, idv, tile);
     if (ADD2 && pl.step[0].seg2 >= 0) {
       const int s2 = pl.step[0].seg2;
 #pragma unroll
       for (int s = 0; s < GNC_MAX_SEGMENTS; ++s) idv = s == s2 ? ids[s] : idv;
-      load_rows(cur2, s2, pl.step[0].c0, idv);
+      load_rows(cur2, s2, pl.step[0].c0, idv, tile);
     }
   }
   // weight chunk 0 -> buffer 0
@@ -210,11 +232,11 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_stream_kernel(const gnc_mlp_de
         int idv = 0;
 #pragma unroll
         for (int k = 0; k < GNC_MAX_SEGMENTS; ++k) idv = k == ns ? ids[k] : idv;
-        load_rows(cur, ns, nc0, idv);
+        load_rows(cur, ns, nc0, idv, wrap ? ntile : tile);
         if (ADD2 && ns2 >= 0) {
 #pragma unroll
           for (int k = 0; k < GNC_MAX_SEGMENTS; ++k) idv = k == ns2 ? ids[k] : idv;
-          load_rows(cur2, ns2, nc0, idv);
+          load_rows(cur2, ns2, nc0, idv, wrap ? ntile : tile);
         }
       }
       if (additive) {
@@ -293,28 +315,8 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_stream_kernel(const gnc_mlp_de
           default: chunk_to_lds<OT, 6>(o, abuf, i, h); break;
         }
         compiler_lds_barrier();
-        const int col = cc * KC + c4 * 4;
-        const bool col_ok = col < out_dim;
-        const int colc = col_ok ? col : 0;
-        const bool vec_out = (out_dim % 4 == 0) && (d.ld_out % 4 == 0) && ((reinterpret_cast<uintptr_t>(d.out) & 15u) == 0);
-        f32x4 (&outv)[NP] = cur2;  // free here: a tile always starts with a MATMUL step, which uses `cur` only
-#pragma unroll
-        for (int p = 0; p < NP; ++p) outv[p] = *reinterpret_cast<const f32x4*>(abuf + (p * 4 + rs) * LDSW + c4 * 4);
-        if (d.residual) {  // rows this tile read a moment ago (L2 hits); unconditional, clamped
-          const int rc = colc < d.ld_residual ? colc : 0;
-#pragma unroll
-          for (int p = 0; p < NP; ++p) {
-            int r = row0 + p * 4 + rs;
-            r = r < rows ? r : rows - 1;
-            outv[p] += *reinterpret_cast<const f32x4*>(d.residual + (int64_t)r * d.ld_residual + rc);
-          }
-        }
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-          const int r = row0 + p * 4 + rs;
-          store_row_piece(d.out + (int64_t)(r < rows ? r : rows - 1) * d.ld_out, col, outv[p], r < rows && col_ok,
-                          out_dim, vec_out);
-        }
+        store_staged_rows(abuf, d.out + cc * KC, d.ld_out, out_dim - cc * KC < KC ? out_dim - cc * KC : KC, row0, rows, c4, rs,
+                          d.residual ? d.residual + cc * KC : nullptr, d.ld_residual);
       }
     }
     compiler_lds_barrier();

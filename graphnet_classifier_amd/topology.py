@@ -42,8 +42,9 @@ class GraphTopology:
         self.rowptr, self.perm, status = native.csr_build(col, self.num_nodes)
         self.src_sorted = native.permute_index(row, self.perm)
         self.dst_sorted = native.permute_index(col, self.perm)
-        self.row32 = native.permute_index(row, None)
-        self.col32 = native.permute_index(col, None)
+        self._row, self._col = row, col  # int32 copies in ORIGINAL edge order are built on first use
+        self._row32 = None
+        self._col32 = None
         self._inv_perm = None
         self._csc = None
         if validate:
@@ -53,6 +54,20 @@ class GraphTopology:
             bad_src = bool(((row < 0) | (row >= self.num_nodes)).any().item()) if self.num_edges else False
             if bad_dst or bad_src:
                 raise IndexError(f"edge_index has node ids outside [0, {self.num_nodes})")
+
+    @property
+    def row32(self) -> torch.Tensor:
+        """int32 [E] source ids in original edge order (operator-level calls only)."""
+        if self._row32 is None:
+            self._row32 = native.permute_index(self._row, None)
+        return self._row32
+
+    @property
+    def col32(self) -> torch.Tensor:
+        """int32 [E] destination ids in original edge order (backward of the operator-level scatter_sum)."""
+        if self._col32 is None:
+            self._col32 = native.permute_index(self._col, None)
+        return self._col32
 
     @property
     def inv_perm(self) -> torch.Tensor:
