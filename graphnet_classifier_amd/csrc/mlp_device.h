@@ -189,6 +189,14 @@ __device__ __forceinline__ float add_halves(float x) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);  // lower-half value + upper-half value, in that order
 }
 
+// x summed over the four lanes {l, l^16, l^32, l^48} (the 16-row MFMA layout keeps a row's features on those),
+// on the VALU: v_permlane16_swap exchanges odd 16-lane rows of one register with even rows of another.
+__device__ __forceinline__ float add_quarters(float x) {
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return add_halves(__uint_as_float(r[0]) + __uint_as_float(r[1]));
+}
+
 // LayerNorm over the out_dim features of each data row: registers + one cross-half exchange.
 // fp32 MFMA and VALU instructions do NOT overlap on a gfx950 SIMD (tools/hw_probe.hip: one 32x32x2 MFMA
 // + k VALU = 64 + ~3..5k cycles), so the instruction count here is kernel time: packed fp32 math, no
@@ -481,18 +489,18 @@ __device__ __forceinline__ void hidden_window_store(f32x4 v, uint32_t byte_off, 
 // A tile's eight 4-row pieces through windows.  Full tiles: ONE window, the piece offset rides in the
 // instruction's SGPR offset (1 SALU per piece, no VGPR, but that field is not bounds-checked).  The last tile
 // and anything beyond the table: one window per piece, so the bounds check sees the row.
-template <bool STREAM = false>
-__device__ __forceinline__ void load_tile_rows(f32x4 (&pre)[8], const float* base, int ld, int64_t row0, int64_t rows,
+template <bool STREAM = false, int PIECES = 8>
+__device__ __forceinline__ void load_tile_rows(f32x4 (&pre)[PIECES], const float* base, int ld, int64_t row0, int64_t rows,
                                                uint32_t lane_off) {
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-  if (row0 + 32 <= rows) {
+  if (row0 + 4 * PIECES <= rows) {
     const __amdgpu_buffer_rsrc_t w = row_window(base, row0, rows, ld);
 #pragma unroll
-    for (int p = 0; p < 8; ++p)
+    for (int p = 0; p < PIECES; ++p)
       pre[p] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(w, lane_off, p * 16 * ld, STREAM ? 2 : 0));
   } else {
 #pragma unroll
-    for (int p = 0; p < 8; ++p)
+    for (int p = 0; p < PIECES; ++p)
       pre[p] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(row_window(base, row0 + 4 * p, rows, ld),
                                                                                      lane_off, 0, STREAM ? 2 : 0));
   }
@@ -511,36 +519,37 @@ __device__ __forceinline__ void hidden_window_store_s(f32x4 v, uint32_t byte_off
 // one output row group (declared below)
 __device__ __forceinline__ void store_row_piece(float* rowp, int col, f32x4 v, bool row_ok, int out_dim, bool vec_out);
 
-// The wave's staged [32][64] LDS tile -> columns [0, width) of rows row0.. of dst ([rows, ld]; dst may point at a
+// The wave's staged [4*PIECES][64] LDS tile -> columns [0, width) of rows row0.. of dst ([rows, ld]; dst may point at a
 // column offset inside a wider tensor), optionally + the same rows of `add` ([rows, ld_add], first 64 columns).
 // Vector case (width % 4 == 0, ld % 4 == 0, 16-B aligned): windows as in load_tile_rows, no VALU per store,
 // rows past the end dropped by the bounds check; otherwise the masked scalar path.
+template <int PIECES = NP>
 __device__ __forceinline__ void store_staged_rows(const float* abuf, float* dst, int ld, int width, int row0, int rows,
                                                   int c4, int rs, const float* add = nullptr, int ld_add = 0) {
   const int col = c4 * 4;
   const bool vec = (width % 4 == 0) && (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0);
   const float* src = abuf + rs * LDSW + col;
   if (add) {  // rows this tile has read before: L2 hits; rows past the end read as 0
-    f32x4 v[NP];
+    f32x4 v[PIECES];
     const uint32_t aoff = (uint32_t)(rs * ld_add + (col < width ? col : 0)) * 4u;  // lanes beyond `width` are not stored
-    load_tile_rows(v, add, ld_add, row0, rows, aoff);
+    load_tile_rows<false, PIECES>(v, add, ld_add, row0, rows, aoff);
     if (vec) {
       const uint32_t off = (uint32_t)(rs * ld + col) * 4u;
       if (col < width) {
-        if (row0 + RPW <= rows) {
+        if (row0 + 4 * PIECES <= rows) {
           const __amdgpu_buffer_rsrc_t w = row_window(dst, row0, rows, ld);
 #pragma unroll
-          for (int p = 0; p < NP; ++p)
+          for (int p = 0; p < PIECES; ++p)
             hidden_window_store_s(v[p] + *reinterpret_cast<const f32x4*>(src + p * 4 * LDSW), off, w, (uint32_t)(p * 16 * ld));
         } else {
 #pragma unroll
-          for (int p = 0; p < NP; ++p)
+          for (int p = 0; p < PIECES; ++p)
             hidden_window_store(v[p] + *reinterpret_cast<const f32x4*>(src + p * 4 * LDSW), off, row_window(dst, row0 + 4 * p, rows, ld));
         }
       }
     } else {
 #pragma unroll
-      for (int p = 0; p < NP; ++p) {
+      for (int p = 0; p < PIECES; ++p) {
         const int r = row0 + p * 4 + rs;
         store_row_piece(dst + (int64_t)(r < rows ? r : rows - 1) * ld, col, v[p] + *reinterpret_cast<const f32x4*>(src + p * 4 * LDSW),
                         r < rows && col < width, width, false);
@@ -551,20 +560,20 @@ __device__ __forceinline__ void store_staged_rows(const float* abuf, float* dst,
   if (vec) {  // one piece at a time: 4 live registers, the asm stores keep the order
     const uint32_t off = (uint32_t)(rs * ld + col) * 4u;
     if (col < width) {
-      if (row0 + RPW <= rows) {
+      if (row0 + 4 * PIECES <= rows) {
         const __amdgpu_buffer_rsrc_t w = row_window(dst, row0, rows, ld);
 #pragma unroll
-        for (int p = 0; p < NP; ++p)
+        for (int p = 0; p < PIECES; ++p)
           hidden_window_store_s(*reinterpret_cast<const f32x4*>(src + p * 4 * LDSW), off, w, (uint32_t)(p * 16 * ld));
       } else {
 #pragma unroll
-        for (int p = 0; p < NP; ++p)
+        for (int p = 0; p < PIECES; ++p)
           hidden_window_store(*reinterpret_cast<const f32x4*>(src + p * 4 * LDSW), off, row_window(dst, row0 + 4 * p, rows, ld));
       }
     }
   } else {
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {
+    for (int p = 0; p < PIECES; ++p) {
       const int r = row0 + p * 4 + rs;
       store_row_piece(dst + (int64_t)(r < rows ? r : rows - 1) * ld, col, *reinterpret_cast<const f32x4*>(src + p * 4 * LDSW),
                       r < rows && col < width, width, false);

@@ -107,36 +107,45 @@ __device__ __forceinline__ void mma16_chunk_from_regs(f32x4 (&dst)[NTO], const f
   }
 }
 
+// Same instruction diet as layer_norm_tiles (mlp_device.h): packed fp32 math, features >= out_dim hold exact
+// zeros and drop out of the sums without selects, 1/n as a multiplier, v_rsq_f32, cross-lane sums on the VALU.
 template <int NTL>
 __device__ __forceinline__ void layer_norm16(f32x4 (&o)[NTL], const float* pg, const float* pbt, int out_dim, float eps,
                                              int g) {
-  float s = 0.f;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const float inv_n = 1.f / (float)out_dim;
+  f32x2 sa = {0.f, 0.f}, sb = {0.f, 0.f};
 #pragma unroll
   for (int t = 0; t < NTL; ++t) {
-    const int f = 16 * t + 4 * g;
-    s += (f + 0 < out_dim ? o[t].x : 0.f) + (f + 1 < out_dim ? o[t].y : 0.f) + (f + 2 < out_dim ? o[t].z : 0.f) +
-         (f + 3 < out_dim ? o[t].w : 0.f);
+    sa += f32x2{o[t].x, o[t].y};
+    sb += f32x2{o[t].z, o[t].w};
   }
-  s += __shfl_xor(s, 16, 64);
-  s += __shfl_xor(s, 32, 64);
-  const float mean = s / (float)out_dim;
-  float v = 0.f;
+  const float mean = add_quarters((sa.x + sa.y) + (sb.x + sb.y)) * inv_n;
+  const f32x4 m4 = {mean, mean, mean, mean};
+#pragma unroll
+  for (int t = 0; t < NTL; ++t) o[t] -= m4;
+  if (out_dim != NTL * 16) {  // wave-uniform and rare: clear the deviations of the padding features
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) {
+      const int f = 16 * t + 4 * g;
+      o[t].x = f + 0 < out_dim ? o[t].x : 0.f; o[t].y = f + 1 < out_dim ? o[t].y : 0.f;
+      o[t].z = f + 2 < out_dim ? o[t].z : 0.f; o[t].w = f + 3 < out_dim ? o[t].w : 0.f;
+    }
+  }
+  f32x2 va = {0.f, 0.f}, vb = {0.f, 0.f};
 #pragma unroll
   for (int t = 0; t < NTL; ++t) {
-    const int f = 16 * t + 4 * g;
-    const float d0 = o[t].x - mean, d1 = o[t].y - mean, d2 = o[t].z - mean, d3 = o[t].w - mean;
-    v += (f + 0 < out_dim ? d0 * d0 : 0.f) + (f + 1 < out_dim ? d1 * d1 : 0.f) + (f + 2 < out_dim ? d2 * d2 : 0.f) +
-         (f + 3 < out_dim ? d3 * d3 : 0.f);
+    const f32x2 da = {o[t].x, o[t].y}, db = {o[t].z, o[t].w};
+    va = __builtin_elementwise_fma(da, da, va);
+    vb = __builtin_elementwise_fma(db, db, vb);
   }
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 32, 64);
-  const float rstd = 1.f / sqrtf(v / (float)out_dim + eps);
+  const float rstd = __frsqrt_rn(add_quarters((va.x + va.y) + (vb.x + vb.y)) * inv_n + eps);
+  const f32x4 r4 = {rstd, rstd, rstd, rstd};
 #pragma unroll
   for (int t = 0; t < NTL; ++t) {
     const f32x4 gm = *reinterpret_cast<const f32x4*>(pg + 16 * t + 4 * g);
     const f32x4 bt = *reinterpret_cast<const f32x4*>(pbt + 16 * t + 4 * g);
-    o[t].x = (o[t].x - mean) * rstd * gm.x + bt.x; o[t].y = (o[t].y - mean) * rstd * gm.y + bt.y;
-    o[t].z = (o[t].z - mean) * rstd * gm.z + bt.z; o[t].w = (o[t].w - mean) * rstd * gm.w + bt.w;
+    o[t] = __builtin_elementwise_fma(o[t], gm * r4, bt);
   }
 }
 
@@ -177,8 +186,19 @@ __global__ __launch_bounds__(NT16) void mlp_stream16_kernel(const gnc_mlp_desc_t
     const int ldw = ldw_of(d, layer);
     const int nrows = d.out_dim[layer];
     const int klimit = pl.wc[q].klimit;
-    const int col = pl.wc[q].kbase + wc4 * 4;
-    const int colc = col < klimit ? col : pl.wc[q].kbase;
+    const int kbase = pl.wc[q].kbase;
+    if (kbase + KC <= klimit && ldw % 4 == 0 && (reinterpret_cast<uintptr_t>(W) & 15u) == 0 &&
+        (int64_t)nrows * ldw * 4 <= 0xffffffffll) {
+      // full 64-column chunk of an aligned matrix: window over the matrix (rows >= nrows read as 0), no masks
+      const __amdgpu_buffer_rsrc_t w =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, nrows * ldw * 4, 0x00020000);
+      const uint32_t off0 = (uint32_t)(wr0 * ldw + kbase + wc4 * 4) * 4u;
+#pragma unroll
+      for (int p = 0; p < NW; ++p) wr[p] = window_load(w, off0 + (uint32_t)(p * RPP * 4) * (uint32_t)ldw);
+      return;
+    }
+    const int col = kbase + wc4 * 4;
+    const int colc = col < klimit ? col : kbase;
 #pragma unroll
     for (int p = 0; p < NW; ++p) {
       const int n = p * RPP + wr0;
@@ -202,25 +222,34 @@ __global__ __launch_bounds__(NT16) void mlp_stream16_kernel(const gnc_mlp_desc_t
     const int32_t* ip = d.seg[s].index;
     return ip ? ip[r] : r;
   };
-  auto load_rows = [&](f32x4 (&pre)[NP16], int s, int c0, int idxv) {
+  auto load_rows = [&](f32x4 (&pre)[NP16], int s, int c0, int idxv, int tile_of) {
     const float* base = d.seg[s].ptr;
     const int ld = d.seg[s].ld;
     const int col = c0 + c4 * 4 < ld ? c0 + c4 * 4 : 0;
+    if (d.seg[s].index == nullptr) {  // row-ordered: window at the tile's first row
+      load_tile_rows<false, NP16>(pre, base, ld, ((int64_t)tile_of * W16 + wave) * R16, rows, (uint32_t)(rs * ld + col) * 4u);
+    } else {
 #pragma unroll
-    for (int p = 0; p < NP16; ++p) {
-      const int tr = __shfl(idxv, p * 4 + rs, 64);
-      pre[p] = *reinterpret_cast<const f32x4*>(base + (int64_t)tr * ld + col);
+      for (int p = 0; p < NP16; ++p) {
+        const int tr = __shfl(idxv, p * 4 + rs, 64);
+        pre[p] = *reinterpret_cast<const f32x4*>(base + (int64_t)tr * ld + col);
+      }
     }
   };
   auto stage = [&](const f32x4 (&pre)[NP16], int c0, int width) {
     compiler_lds_barrier();
     const int c = c0 + c4 * 4;
+    if (c0 + KC <= width) {  // full chunk: nothing to mask
 #pragma unroll
-    for (int p = 0; p < NP16; ++p) {
-      f32x4 v = pre[p];
-      v.x = c + 0 < width ? v.x : 0.f; v.y = c + 1 < width ? v.y : 0.f;
-      v.z = c + 2 < width ? v.z : 0.f; v.w = c + 3 < width ? v.w : 0.f;
-      *reinterpret_cast<f32x4*>(abuf + (p * 4 + rs) * LDSW + c4 * 4) = v;
+      for (int p = 0; p < NP16; ++p) *reinterpret_cast<f32x4*>(abuf + (p * 4 + rs) * LDSW + c4 * 4) = pre[p];
+    } else {
+#pragma unroll
+      for (int p = 0; p < NP16; ++p) {
+        f32x4 v = pre[p];
+        v.x = c + 0 < width ? v.x : 0.f; v.y = c + 1 < width ? v.y : 0.f;
+        v.z = c + 2 < width ? v.z : 0.f; v.w = c + 3 < width ? v.w : 0.f;
+        *reinterpret_cast<f32x4*>(abuf + (p * 4 + rs) * LDSW + c4 * 4) = v;
+      }
     }
     compiler_lds_barrier();
   };
@@ -239,7 +268,7 @@ __global__ __launch_bounds__(NT16) void mlp_stream16_kernel(const gnc_mlp_desc_t
     return v;
   };
   f32x4 cur[NP16];
-  load_rows(cur, pl.step[0].seg, pl.step[0].c0, id_of(pl.step[0].seg));
+  load_rows(cur, pl.step[0].seg, pl.step[0].c0, id_of(pl.step[0].seg), tile);
   f32x4 wreg[NW];
   wload(wreg, 0);
   wstore(wreg, wbuf);
@@ -280,7 +309,7 @@ __global__ __launch_bounds__(NT16) void mlp_stream16_kernel(const gnc_mlp_desc_t
             if (k < d.num_segments) ids_next[k] = load_idx(ntile + (int)gridDim.x, k);
           }
         }
-        load_rows(cur, pl.step[nst].seg, pl.step[nst].c0, id_of(pl.step[nst].seg));
+        load_rows(cur, pl.step[nst].seg, pl.step[nst].c0, id_of(pl.step[nst].seg), wrap ? ntile : tile);
       }
       if (pl.step[st].add) {  // rows already in the hidden width: acc[t] += staged columns (tile t = c0/16 + cb)
         const int t0 = c0 >> 4;
@@ -347,7 +376,6 @@ __global__ __launch_bounds__(NT16) void mlp_stream16_kernel(const gnc_mlp_desc_t
     for (int p = 0; p < NP16; ++p) asm volatile("" ::"v"(cur[p]));
 
     // ------------------------------------------------------------------ epilogue: 64 output columns at a time
-    const bool vec_out = (out_dim % 4 == 0) && (d.ld_out % 4 == 0) && ((reinterpret_cast<uintptr_t>(d.out) & 15u) == 0);
 #pragma unroll
     for (int cc = 0; cc < NCHO; ++cc) {
       if (cc * KC < out_dim) {
@@ -356,27 +384,8 @@ __global__ __launch_bounds__(NT16) void mlp_stream16_kernel(const gnc_mlp_desc_t
         for (int cb = 0; cb < 4; ++cb)
           if (4 * cc + cb < NTO) *reinterpret_cast<f32x4*>(abuf + i * LDSW + 16 * cb + 4 * g) = o[4 * cc + cb < NTO ? 4 * cc + cb : 0];
         compiler_lds_barrier();
-        const int col = cc * KC + c4 * 4;
-        const bool col_ok = col < out_dim;
-        const int colc = col_ok ? col : 0;
-        f32x4 outv[NP16];
-#pragma unroll
-        for (int p = 0; p < NP16; ++p) outv[p] = *reinterpret_cast<const f32x4*>(abuf + (p * 4 + rs) * LDSW + c4 * 4);
-        if (d.residual) {
-          const int rc = colc < d.ld_residual ? colc : 0;
-#pragma unroll
-          for (int p = 0; p < NP16; ++p) {
-            int r = row0 + p * 4 + rs;
-            r = r < rows ? r : rows - 1;
-            outv[p] += *reinterpret_cast<const f32x4*>(d.residual + (int64_t)r * d.ld_residual + rc);
-          }
-        }
-#pragma unroll
-        for (int p = 0; p < NP16; ++p) {
-          const int r = row0 + p * 4 + rs;
-          store_row_piece(d.out + (int64_t)(r < rows ? r : rows - 1) * d.ld_out, col, outv[p], r < rows && col_ok, out_dim,
-                          vec_out);
-        }
+        store_staged_rows<NP16>(abuf, d.out + cc * KC, d.ld_out, out_dim - cc * KC < KC ? out_dim - cc * KC : KC, row0, rows, c4,
+                                rs, d.residual ? d.residual + cc * KC : nullptr, d.ld_residual);
       }
     }
     compiler_lds_barrier();
