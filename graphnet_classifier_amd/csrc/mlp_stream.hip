@@ -126,10 +126,20 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_stream_kernel(const gnc_mlp_de
     if (d.seg[s].index == nullptr) {
       load_tile_rows(pre, base, ld, ((int64_t)tile_of * WAVES + wave) * RPW, rows, (uint32_t)(rs * ld + col) * 4u);
     } else {
+      const int64_t tbytes = d.seg[s].table_rows * (int64_t)ld * 4;
+      if (tbytes > 0 && tbytes <= 0xffffffffll) {
+        // stated table below 4 GiB: bounds-checked window over the table, the row's byte offset travels by
+        // ds_bpermute, one 32-bit add per access (an id outside the table reads zeros)
+        const __amdgpu_buffer_rsrc_t w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)(uint32_t)tbytes, 0x00020000);
+        const int row_bytes = idxv * (ld * 4);
 #pragma unroll
-      for (int p = 0; p < NP; ++p) {
-        const int tr = __shfl(idxv, p * 4 + rs, 64);
-        pre[p] = *reinterpret_cast<const f32x4*>(base + (int64_t)tr * ld + col);
+        for (int p = 0; p < NP; ++p) pre[p] = window_load(w, (uint32_t)__shfl(row_bytes, p * 4 + rs, 64) + (uint32_t)(col * 4));
+      } else {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const int tr = __shfl(idxv, p * 4 + rs, 64);
+          pre[p] = *reinterpret_cast<const f32x4*>(base + (int64_t)tr * ld + col);
+        }
       }
     }
   };
