@@ -26,6 +26,9 @@ from .topology import GraphTopology, get_topology
 # Algebraic split of the edge processor's first Linear (DESIGN.md, K4 "W-split"); GNC_NO_WSPLIT=1
 # keeps the reference-form concat for A/B measurements.
 WSPLIT = os.environ.get("GNC_NO_WSPLIT") is None
+# Inference: the edge processor's launch also forms the node model's per-destination sums (fused aggregation
+# epilogue); GNC_NO_FUSED_AGG=1 keeps K1 as a separate launch for A/B measurements.
+FUSED_AGG = os.environ.get("GNC_NO_FUSED_AGG") is None
 
 
 # --------------------------------------------------------------------------- a1 scatter_sum
@@ -68,9 +71,11 @@ class EdgeProcessor(nn.Module):
         out = self.edge_processor.forward_segments([(src, None), (dest, None), (edge_attr, None)], residual=edge_attr)
         return out if back == dev else out.to(back)
 
-    def forward_sorted(self, x: Tensor, topo: GraphTopology, edge_attr: Tensor) -> Tensor:
+    def forward_sorted(self, x: Tensor, topo: GraphTopology, edge_attr: Tensor, aggregate: bool = False):
         """Same math with the two row gathers fused into the kernel; ``edge_attr`` and the
-        result are in destination-sorted edge order."""
+        result are in destination-sorted edge order.  ``aggregate=True`` (inference only) returns
+        ``(e', agg)`` where ``agg`` is the per-destination sum of ``e'`` formed in the same launch, or None
+        when that launch cannot carry it."""
         mlp = self.edge_processor
         norm = mlp.model[-1] if mlp.norm_type is not None else None
         lin = mlp._linears()
@@ -78,10 +83,14 @@ class EdgeProcessor(nn.Module):
                 and lin[0].in_features == 2 * x.size(1) + edge_attr.size(1) and x.size(1) % 4 == 0):
             # W-split of the first Linear: node-side products once per node, gathered and added per edge
             ln = (norm.weight, norm.bias, norm.eps) if isinstance(norm, nn.LayerNorm) else None
+            if aggregate:
+                return Fn.edge_processor_wsplit_aggregated(x, edge_attr, topo, [m.weight for m in lin], [m.bias for m in lin],
+                                                           ln, mlp.activation_name, mlp._act_param())
             return Fn.edge_processor_wsplit(x, edge_attr, topo, [m.weight for m in lin],
                                             [m.bias for m in lin], ln, mlp.activation_name, mlp._act_param())
-        return mlp.forward_segments(
+        out = mlp.forward_segments(
             [(x, topo.src_sorted), (x, topo.dst_sorted), (edge_attr, None)], residual=edge_attr, rows=topo.num_edges)
+        return (out, None) if aggregate else out
 
 
 # --------------------------------------------------------------------------- a2 NodeProcessor
@@ -103,8 +112,10 @@ class NodeProcessor(nn.Module):
         out = self.node_processor.forward_segments([(x, None), (agg, None)], residual=x)
         return out if back == dev else out.to(back)
 
-    def forward_sorted(self, x: Tensor, topo: GraphTopology, edge_attr: Tensor) -> Tensor:
-        agg = Fn.scatter_sum_csr(edge_attr, topo.rowptr, None, topo.dst_sorted, topo.num_nodes)
+    def forward_sorted(self, x: Tensor, topo: GraphTopology, edge_attr: Tensor, agg: Tensor | None = None) -> Tensor:
+        """``agg`` given: the per-destination sums already formed by the edge launch's epilogue."""
+        if agg is None:
+            agg = Fn.scatter_sum_csr(edge_attr, topo.rowptr, None, topo.dst_sorted, topo.num_nodes)
         return self.node_processor.forward_segments([(x, None), (agg, None)], residual=x)
 
 
@@ -136,10 +147,20 @@ class MetaLayer(nn.Module):
         return x, edge_attr, u
 
     def forward_sorted(self, x: Tensor, topo: GraphTopology, edge_attr: Tensor):
+        agg = None
         if self.edge_model is not None:
-            edge_attr = self.edge_model.forward_sorted(x, topo, edge_attr)
+            # inference: let the edge launch form the node model's aggregate in its epilogue;
+            # with autograd on, K1 stays a separate differentiable launch
+            if (FUSED_AGG and self.node_model is not None and not torch.is_grad_enabled()
+                    and isinstance(self.edge_model, EdgeProcessor) and isinstance(self.node_model, NodeProcessor)):
+                edge_attr, agg = self.edge_model.forward_sorted(x, topo, edge_attr, aggregate=True)
+            else:
+                edge_attr = self.edge_model.forward_sorted(x, topo, edge_attr)
         if self.node_model is not None:
-            x = self.node_model.forward_sorted(x, topo, edge_attr)
+            if agg is not None:
+                x = self.node_model.forward_sorted(x, topo, edge_attr, agg)
+            else:
+                x = self.node_model.forward_sorted(x, topo, edge_attr)
         return x, edge_attr
 
 

@@ -680,7 +680,8 @@ inline int tiles_for(int width) {
 int validate_desc(const gnc_mlp_desc_t* d, bool check_ptrs);
 // resident-weights variant (mlp_resident.hip): returns GNC_ERR_UNSUPPORTED when the weights
 // do not fit in LDS, in which case the caller falls through to the streaming kernel
-int launch_resident(const gnc_mlp_desc_t& d, int T, bool narrow_out, hipStream_t stream, bool* launched);
+int launch_resident(const gnc_mlp_desc_t& d, int T, bool narrow_out, hipStream_t stream, bool* launched,
+                    bool probe_only = false);
 // streaming FAST variant (mlp_stream.hip) for widths whose weights do not fit in LDS; same contract
 int launch_stream(const gnc_mlp_desc_t& d, int T, bool narrow_out, hipStream_t stream, bool* launched);
 // widths 129..256 on v_mfma_f32_16x16x4_f32, 16 rows per wave (mlp_stream16.hip); same contract

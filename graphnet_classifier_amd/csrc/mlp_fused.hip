@@ -251,6 +251,34 @@ extern "C" size_t gnc_sizeof_mlp_desc(void) { return sizeof(gnc_mlp_desc_t); }
 
 extern "C" int gnc_mlp_supported(const gnc_mlp_desc_t* desc) { return validate_desc(desc, false); }
 
+// shape-only answer for the fused aggregation epilogue: would the weights-resident kernel take this description
+// with agg_out set?  (pointer fields are used for alignment / aliasing tests only, never dereferenced)
+extern "C" int gnc_mlp_agg_supported(const gnc_mlp_desc_t* desc) {
+  int rc = validate_desc(desc, false);
+  if (rc) return rc;
+  const int L = desc->num_linear;
+  int T = tiles_for(desc->out_dim[0]);
+  const int od = desc->out_dim[L - 1];
+  const bool narrow_out = od <= 32;
+  if (!narrow_out && tiles_for(od) > T) T = tiles_for(od);
+  gnc_mlp_desc_t probe = *desc;
+  int32_t dummy_i = 0;
+  float dummy_f = 0.f;
+  if (!probe.agg_out) probe.agg_out = &dummy_f;
+  if (!probe.agg_index) probe.agg_index = &dummy_i;
+  if (!probe.agg_fix) probe.agg_fix = &dummy_i;
+  if (probe.ld_agg < od) probe.ld_agg = od;
+  bool ok = false;
+  rc = launch_resident(probe, T, narrow_out, nullptr, &ok, true);
+  if (rc) return rc;
+  if (!ok) {
+    gnc::set_error("gnc_mlp_agg_supported: needs the weights-resident W-split shape (1 MATMUL + 2 ADD segments, "
+                   "residual = the MATMUL segment, widths 33..64)");
+    return GNC_ERR_UNSUPPORTED;
+  }
+  return GNC_OK;
+}
+
 extern "C" int gnc_mlp_forward_f32(const gnc_mlp_desc_t* desc, void* stream_) {
   int rc = validate_desc(desc, true);
   if (rc) return rc;
@@ -265,6 +293,11 @@ extern "C" int gnc_mlp_forward_f32(const gnc_mlp_desc_t* desc, void* stream_) {
   bool launched = false;  // weights-resident variant first (decides by LDS fit)
   rc = launch_resident(*desc, T, narrow_out, stream, &launched);
   if (rc || launched) return rc;
+  if (desc->agg_out) {
+    gnc::set_error("gnc_mlp_forward_f32: the fused aggregation epilogue is not available for this description "
+                   "(gnc_mlp_agg_supported)");
+    return GNC_ERR_UNSUPPORTED;
+  }
   static const bool s16_128 = getenv("GNC_STREAM16_D128") != nullptr;  // A/B: 16-row kernel also for 65..128 features
   if (T == 8 || (T == 4 && s16_128)) {  // 129..256 features: 16-row tiles on the 16x16x4 MFMA
     rc = launch_stream16(*desc, stream, &launched);

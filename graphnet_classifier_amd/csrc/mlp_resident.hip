@@ -69,7 +69,11 @@ constexpr int RNT = RWAVES * 64;
 // HT/OT: accumulator tiles of the hidden / output width.  NMM: MATMUL steps per tile (1..3).
 // NADD: additive segments merged into one step (0 or 2).  RESREG: the residual is the table of
 // the LAST MATMUL step (no index): its rows are kept in registers instead of being re-read.
-template <int HT, int OT, int NMM, int NADD, bool RESREG>
+// AGG: fused aggregation epilogue (gnc_mlp_desc_t.agg_out): every wave walks a CONTIGUOUS range of tiles and
+// carries the running sum of the destination in progress from tile to tile in one register (lane = feature),
+// so a destination's rows are added in ascending order exactly as K1 does; only the first and the last
+// destination of a wave's range (which may continue in a neighbour's range) are left to gnc_agg_fixup_f32.
+template <int HT, int OT, int NMM, int NADD, bool RESREG, bool AGG = false>
 __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t d, const int num_wtiles,
                                                            const int total_chunks) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -164,7 +168,15 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
     compiler_lds_barrier();
   };
 
-  int wt = (int)blockIdx.x * RWAVES + wave;
+  // tile schedule: strided over the grid, or (AGG) one contiguous range [wt, wt_end) per wave
+  const int gwave = (int)blockIdx.x * RWAVES + wave;
+  const int stride = AGG ? 1 : total_waves;
+  int wt = gwave, wt_end = num_wtiles;
+  if constexpr (AGG) {
+    const int q = num_wtiles / total_waves, rem = num_wtiles - q * total_waves;
+    wt = gwave * q + (gwave < rem ? gwave : rem);
+    wt_end = wt + q + (gwave < rem ? 1 : 0);
+  }
   f32x4 cur[NP];                  // rows of the step about to be staged
   f32x4 addA[NADD ? NP : 1], addB[NADD ? NP : 1];
   // row offsets of gathered segments: off0 = segment 0 of the NEXT tile, offs[s>=1] = segment s of the CURRENT tile
@@ -172,18 +184,31 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
   load_rows(cur, sv[0], wt, row_offset(wt, sv[0]));
 #pragma unroll
   for (int s = 1; s < NS; ++s) offs[s] = row_offset(wt, sv[s]);
-  uint32_t off0 = row_offset(wt + total_waves, sv[0]);
+  uint32_t off0 = row_offset(wt + stride, sv[0]);
 
   const int col_out = c4 * 4;
   const bool vec_out = (out_dim % 4 == 0) && (d.ld_out % 4 == 0) && ((reinterpret_cast<uintptr_t>(d.out) & 15u) == 0);
   const uint32_t out_lane_off = (uint32_t)(rs * d.ld_out + col_out) * 4u;
   const uint32_t res_lane_off = (uint32_t)(rs * d.ld_residual + (col_out < d.ld_residual ? col_out : 0)) * 4u;
 
+  // fused aggregation state: destination ids of the tile's rows (lane & 31), running sum (lane = feature)
+  auto agg_ids = [&](int t) -> int {
+    int r = t * RPW + (lane & 31);
+    r = r < rows ? r : rows - 1;
+    return d.agg_index[r];
+  };
+  int aid = 0, aid_next = 0;
+  float agg_acc = 0.f;
+  int agg_cur = -1, agg_first_dst = -1;  // wave-uniform
+  bool agg_first = true;
+  if constexpr (AGG) aid = agg_ids(wt < last_wt ? wt : last_wt);
+
   PROBE_BEGIN();
-  while (wt < num_wtiles) {
+  while (wt < wt_end) {
     PROBE_TILE();
     const int row0 = wt * RPW;
-    const int nwt = wt + total_waves;
+    const int nwt = wt + stride;
+    if constexpr (AGG) aid_next = agg_ids(nwt < last_wt ? nwt : last_wt);
 
     // ------------------------------------------------------------------ first Linear
     f32x16 hid[HT];
@@ -205,7 +230,7 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
           offs[NMM + 1] = row_offset(nwt, sv[NMM + 1]);
         } else {
           load_rows(cur, sv[0], nwt, off0);
-          off0 = row_offset(nwt + total_waves, sv[0]);
+          off0 = row_offset(nwt + stride, sv[0]);
         }
       }
       mma_chunk_from_lds<HT>(hid, abuf, wres + s * CH, (sv[s].width + 7) >> 3, i, h);
@@ -226,7 +251,7 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
       for (int p = 0; p < NP; ++p) sum[p] = addA[p] + addB[p];
       stage(sum, sv[NMM].width);
       load_rows(cur, sv[0], nwt, off0);  // next tile's first step: the rest of this tile to land
-      off0 = row_offset(nwt + total_waves, sv[0]);
+      off0 = row_offset(nwt + stride, sv[0]);
       add_tile_from_lds<HT>(hid, abuf, i, h);
       PROBE(2);  // wait for the gathered rows + ADD step
     }
@@ -266,6 +291,35 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
       PROBE(5);  // LayerNorm + residual + transpose out
     }
     compiler_lds_barrier();
+    if constexpr (AGG) {
+      // The tile's final rows (residual included) sit in the wave's LDS tile.  bnd bit r = "row r starts a new
+      // destination"; everything that steers the walk is wave-uniform (SALU), the vector unit only adds.
+      const int valid = rows - row0 < RPW ? rows - row0 : RPW;
+      int prv = __shfl_up(aid, 1, 64);
+      prv = lane == 0 ? agg_cur : prv;
+      const unsigned long long vmask = valid >= 32 ? 0xffffffffull : ((1ull << valid) - 1ull);
+      const unsigned long long bnd = __ballot(aid != prv) & vmask;
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) {
+        if (r < valid) {
+          if ((bnd >> r) & 1ull) {
+            if (agg_cur >= 0) {
+              if (agg_first) {  // the range's first destination may have begun in the previous range: fix-up's
+                agg_first = false;
+                agg_first_dst = agg_cur;
+              } else if (lane < out_dim) {
+                float* dstp = d.agg_out + (int64_t)agg_cur * d.ld_agg;
+                asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2\n\ts_nop 0" ::"v"(lane * 4), "v"(agg_acc), "s"(dstp) : "memory");
+              }
+            }
+            agg_cur = __builtin_amdgcn_readlane(aid, r);
+            agg_acc = 0.f;
+          }
+          agg_acc += abuf[r * LDSW + lane];
+        }
+      }
+      aid = aid_next;
+    }
     // The compiler's counted vmcnt waits do not know about the asm stores below; make it collect the
     // next tile's prefetched rows (issued >= one Linear ago) BEFORE the stores join the queue, so that
     // no later wait for them has to sit out the stores as well.
@@ -307,15 +361,21 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
     PROBE(6);  // epilogue: rows out
     wt = nwt;
   }
+  if constexpr (AGG) {  // the range's first and last destination (possibly the same, possibly none) go to the fix-up
+    if (lane == 0) {
+      d.agg_fix[2 * gwave] = agg_first ? agg_cur : agg_first_dst;
+      d.agg_fix[2 * gwave + 1] = agg_cur;
+    }
+  }
   PROBE_END();
 }
 
-template <int HT, int OT, int NMM, int NADD, bool RESREG>
+template <int HT, int OT, int NMM, int NADD, bool RESREG, bool AGG = false>
 int launch(const gnc_mlp_desc_t& d, int total_chunks, size_t smem, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
     int rc = gnc::check_hip(
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_resident_kernel<HT, OT, NMM, NADD, RESREG>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_resident_kernel<HT, OT, NMM, NADD, RESREG, AGG>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
         "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc) return rc;
@@ -324,7 +384,8 @@ int launch(const gnc_mlp_desc_t& d, int total_chunks, size_t smem, hipStream_t s
   const int64_t num_wtiles = gnc::ceil_div(d.rows, RPW);
   int64_t grid = gnc::ceil_div(num_wtiles, RWAVES);
   if (grid > gnc::kNumCU) grid = gnc::kNumCU;  // one persistent workgroup per CU
-  mlp_resident_kernel<HT, OT, NMM, NADD, RESREG>
+  if constexpr (AGG) grid = gnc::kNumCU;        // agg_fix has two entries for every wave of the full grid
+  mlp_resident_kernel<HT, OT, NMM, NADD, RESREG, AGG>
       <<<dim3((unsigned)grid), dim3(RNT), smem, stream>>>(d, (int)num_wtiles, total_chunks);
   return gnc::check_launch("mlp_resident_kernel");
 }
@@ -333,7 +394,10 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace
 
-int gnc_mlp::launch_resident(const gnc_mlp_desc_t& d, int T, bool narrow_out, hipStream_t stream, bool* launched) {
+extern "C" int gnc_mlp_agg_fix_len(void) { return 2 * gnc::kNumCU * RWAVES; }
+
+int gnc_mlp::launch_resident(const gnc_mlp_desc_t& d, int T, bool narrow_out, hipStream_t stream, bool* launched,
+                             bool probe_only) {
   *launched = false;
   static const bool disabled = getenv("GNC_MLP_NO_RESIDENT") != nullptr;  // A/B switch for benchmarking
   if (disabled) return GNC_OK;
@@ -367,6 +431,17 @@ int gnc_mlp::launch_resident(const gnc_mlp_desc_t& d, int T, bool narrow_out, hi
   const gnc_mlp_segment_t& lm = d.seg[nmm - 1];
   const bool resreg = d.residual && d.residual == lm.ptr && !lm.index && lm.ld == d.ld_residual && lm.width == od;
 
+  if (d.agg_out) {  // fused aggregation epilogue: the W-split edge processor shape only
+    if (!(nadd == 2 && nmm == 1 && resreg && !narrow_out && d.agg_index && d.agg_fix && d.ld_agg >= od)) return GNC_OK;
+    *launched = true;
+    if (probe_only) return GNC_OK;
+    return T == 2 ? launch<2, 2, 1, 2, true, true>(d, total_chunks, smem, stream)
+                  : launch<1, 1, 1, 2, true, true>(d, total_chunks, smem, stream);
+  }
+  if (probe_only) {
+    *launched = true;
+    return GNC_OK;
+  }
 #define GNC_RES(HT_, NMM_, NADD_)                                                             \
   do {                                                                                        \
     *launched = true;                                                                         \

@@ -88,6 +88,30 @@ __global__ __launch_bounds__(gnc::kBlock) void scatter_sum_csr_vec4(
   }
 }
 
+// Fix-up of the fused aggregation epilogue (mlp_resident.hip): the few destinations cut by a wave's row-range
+// boundary are summed here from the stored rows, one 16-lane group (4 floats per lane, <= 64 features) each.
+__global__ __launch_bounds__(gnc::kBlock) void agg_fixup_kernel(const float* __restrict__ src, int64_t ld_src,
+                                                                const int32_t* __restrict__ rowptr,
+                                                                const int32_t* __restrict__ fix, int32_t n_fix,
+                                                                int32_t num_nodes, int32_t feat_dim,
+                                                                float* __restrict__ out, int64_t ld_out) {
+  const int j = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 4);
+  const int col = (threadIdx.x & 15) * 4;
+  if (j >= n_fix) return;
+  const int32_t v = fix[j];
+  if (v < 0 || v >= num_nodes) return;
+  for (int c = col; c < feat_dim; c += 64) {
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int32_t k = rowptr[v]; k < rowptr[v + 1]; ++k)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (c + q < feat_dim) a[q] += src[(int64_t)k * ld_src + c + q];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (c + q < feat_dim) out[(int64_t)v * ld_out + c + q] = a[q];
+  }
+}
+
 // K1, generic: any feat_dim / alignment; one wave per destination, scalar columns.
 template <bool HAS_PERM>
 __global__ __launch_bounds__(gnc::kBlock) void scatter_sum_csr_scalar(
@@ -229,6 +253,18 @@ extern "C" int gnc_scatter_sum_csr_f32(const float* src, int64_t ld_src, const i
   if (perm)
     return launch_scatter<true>(src, ld_src, rowptr, perm, (int32_t)num_nodes, feat_dim, out, ld_out, stream);
   return launch_scatter<false>(src, ld_src, rowptr, nullptr, (int32_t)num_nodes, feat_dim, out, ld_out, stream);
+}
+
+extern "C" int gnc_agg_fixup_f32(const float* src, int64_t ld_src, const int32_t* rowptr, const int32_t* fix, int32_t n_fix,
+                                 int64_t num_nodes, int32_t feat_dim, float* out, int64_t ld_out, void* stream_) {
+  GNC_REQUIRE(n_fix >= 0 && num_nodes >= 0 && num_nodes < INT32_MAX && feat_dim >= 0, "gnc_agg_fixup_f32: bad sizes");
+  if (n_fix == 0 || feat_dim == 0 || num_nodes == 0) return GNC_OK;
+  GNC_REQUIRE(src && rowptr && fix && out, "gnc_agg_fixup_f32: null pointer");
+  GNC_REQUIRE(ld_src >= feat_dim && ld_out >= feat_dim, "gnc_agg_fixup_f32: leading dimension < feat_dim");
+  const int64_t blocks = gnc::ceil_div((int64_t)n_fix * 16, gnc::kBlock);
+  agg_fixup_kernel<<<dim3((unsigned)blocks), dim3(gnc::kBlock), 0, (hipStream_t)stream_>>>(src, ld_src, rowptr, fix, n_fix,
+                                                                                          (int32_t)num_nodes, feat_dim, out, ld_out);
+  return gnc::check_launch("agg_fixup_kernel");
 }
 
 extern "C" int gnc_gather_rows_f32(const float* table, int64_t ld_table, const int32_t* index, int64_t num_rows,

@@ -303,6 +303,21 @@ def edge_processor_wsplit(x, e, topo, weights, biases, ln, activation="ReLU", ac
     return _EdgeProcessorWSplit.apply(meta, topo, x, e, *args)
 
 
+def edge_processor_wsplit_aggregated(x, e, topo, weights, biases, ln, activation="ReLU", act_param=0.0):
+    """Inference form of ``edge_processor_wsplit`` (no autograd graph): the edge launch also forms the
+    per-destination sums of its output rows in its epilogue (include/gnc_hip.h, ``agg_out``).
+    Returns ``(e', agg)``; ``agg`` is None when the launch shape cannot carry the epilogue (the caller then
+    runs K1).  ``agg`` is bit-identical to ``scatter_sum_csr(e', topo.rowptr)``."""
+    dn = x.size(1)
+    w0 = weights[0]
+    ps = native.mlp_forward([(x, None)], [w0[:, :dn]], [None])
+    pd = native.mlp_forward([(x, None)], [w0[:, dn:2 * dn]], [None])
+    return native.mlp_forward([(ps, topo.src_sorted), (pd, topo.dst_sorted), (e, None)], [w0[:, 2 * dn:]] + list(weights[1:]),
+                              list(biases), ln=ln, activation=activation, act_param=act_param, residual=e, rows=e.size(0),
+                              modes=[native.SEG_ADD, native.SEG_ADD, native.SEG_MATMUL],
+                              aggregate=(topo.dst_sorted, topo.rowptr, topo.num_nodes))
+
+
 def edge_features(pos: torch.Tensor, src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
     """[pos[dst]-pos[src], L1 norm] per edge (models/GNN.py:299-302).  ``pos`` is input data
     (utils/dataloader.py:50); gradients with respect to it are not provided."""

@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 GNC_MAX_SEGMENTS = 4
 GNC_MAX_LINEAR = 8
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 ACTIVATIONS = {  # nn.<Name> accepted by the reference's MLP(activation=...) (models/MLP.py:21)
     "ReLU": 0, "Identity": 1, "Tanh": 2, "Sigmoid": 3, "SiLU": 4, "GELU": 5, "LeakyReLU": 6, "ELU": 7,
@@ -29,6 +29,10 @@ _SIGNATURES = {
     "gnc_abi_version": (c_int32, []),
     "gnc_last_error_string": (c_char_p, []),
     "gnc_target_arch": (c_char_p, []),
+    "gnc_mlp_agg_supported": (c_int32, [c_void_p]),
+    "gnc_mlp_agg_fix_len": (c_int32, []),
+    "gnc_agg_fixup_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p, c_int64,
+                                    c_void_p]),
     "gnc_csr_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "gnc_csr_build": (c_int32, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "gnc_permute_index_i64_i32": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
@@ -73,6 +77,7 @@ class MlpDesc(Structure):
         ("residual", c_void_p), ("ld_residual", c_int32),
         ("out", c_void_p), ("ld_out", c_int32),
         ("rows", c_int64),
+        ("agg_out", c_void_p), ("ld_agg", c_int32), ("agg_index", c_void_p), ("agg_fix", c_void_p),
     ]
 
 
@@ -366,16 +371,30 @@ def _prepare_mlp(segments, weights, biases, residual, rows, modes):
 
 
 def mlp_forward(segments, weights, biases, ln=None, activation: str = "ReLU", act_param: float = 0.0,
-                residual: torch.Tensor | None = None, rows: int | None = None, modes=None) -> torch.Tensor:
+                residual: torch.Tensor | None = None, rows: int | None = None, modes=None, aggregate=None):
     """Fused MLP.  segments (in CONCAT order): list of (table [*, w] fp32, index int32 [rows] | None);
     ``modes[s]`` is SEG_MATMUL (default) or SEG_ADD.  Weights may be column slices of a larger
     matrix.  The segment that is also the residual is listed last for the kernel (its weight
-    columns are carried in ``wcol``), so the residual comes from the staged rows."""
+    columns are carried in ``wcol``), so the residual comes from the staged rows.
+
+    ``aggregate=(dst_of_row int32 [rows] non-decreasing, rowptr int32 [N+1], N)`` asks for the fused aggregation
+    epilogue: returns ``(out, agg)`` with ``agg[v] = sum of out rows with dst v`` in row order,
+    bit-identical to ``scatter_sum_csr(out, rowptr)``; returns ``(out, None)`` when the launch shape cannot
+    carry it (the caller then runs K1)."""
     lib = load_library()
     segs, weights, biases, residual, rows, modes = _prepare_mlp(segments, weights, biases, residual, rows, modes)
     dev = segs[0][0].device
     out = torch.empty(rows, weights[-1].size(0), dtype=torch.float32, device=dev)
     desc = make_mlp_desc(segs, weights, biases, ln, activation, act_param, residual, out, rows)
+    agg = fix = None
+    if aggregate is not None:
+        dst_of_row, rowptr, num_nodes = aggregate
+        _require_cuda(dst_of_row, rowptr)
+        if rows > 0 and lib.gnc_mlp_agg_supported(ctypes.byref(desc)) == 0:
+            agg = torch.zeros(num_nodes, out.size(1), dtype=torch.float32, device=dev)  # rows of empty destinations
+            fix = torch.empty(lib.gnc_mlp_agg_fix_len(), dtype=torch.int32, device=dev)
+            desc.agg_out, desc.ld_agg = agg.data_ptr(), _ld(agg)
+            desc.agg_index, desc.agg_fix = dst_of_row.contiguous().data_ptr(), fix.data_ptr()
     # executed FLOPs of this launch: 2 * rows * sum(in*out) over the Linear layers
     flops = 2.0 * rows * sum(w.size(0) * w.size(1) for w in weights)
     with torch.cuda.device(dev):
@@ -384,7 +403,10 @@ def mlp_forward(segments, weights, biases, ln=None, activation: str = "ReLU", ac
                        f"_out{weights[-1].size(0)}_L{len(weights)}", out,
                        lambda: lib.gnc_mlp_forward_f32(ctypes.byref(desc), _stream(out)), flops),
                "gnc_mlp_forward_f32")
-    return out
+        if agg is not None:  # the destinations cut by a wave-range boundary, from the stored rows (same stream)
+            _check(lib.gnc_agg_fixup_f32(out.data_ptr(), _ld(out), rowptr.data_ptr(), fix.data_ptr(), fix.numel(), num_nodes,
+                                         out.size(1), agg.data_ptr(), _ld(agg), _stream(out)), "gnc_agg_fixup_f32")
+    return (out, agg) if aggregate is not None else out
 
 
 # --------------------------------------------------------------------------- K8 backward

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GNC_ABI_VERSION 8
+#define GNC_ABI_VERSION 9
 
 enum {
   GNC_OK = 0,
@@ -164,6 +164,21 @@ typedef struct gnc_mlp_desc {
   float* out;            /* [rows, ld_out]                                 */
   int32_t ld_out;
   int64_t rows;
+  /* Fused aggregation epilogue ("CSR-ordered segmented-sum epilogue"); all NULL / 0 = off.
+   * With agg_out set, the launch ALSO forms agg_out[v, :] = sum of the output rows r with agg_index[r] == v,
+   * added in ascending r starting from 0.0 - bit for bit what gnc_scatter_sum_csr_f32 gives on `out` -
+   * for every destination whose rows lie inside ONE wave's contiguous row range.  Contract:
+   *   - agg_index [rows] int32 is non-decreasing (rows are in destination-CSR order);
+   *   - the caller zero-fills agg_out first (destinations without rows are never written);
+   *   - destinations cut by a range boundary are not written either: the kernel lists them (and -1 for
+   *     idle waves) in agg_fix [gnc_mlp_agg_fix_len()] int32, and gnc_agg_fixup_f32 recomputes exactly
+   *     those rows from `out` through the row pointers afterwards (same stream).
+   * Served by the weights-resident kernel only (out_dim <= 64, residual = last MATMUL segment or none):
+   * ask gnc_mlp_agg_supported(); gnc_mlp_forward_f32 returns GNC_ERR_UNSUPPORTED otherwise. */
+  float* agg_out;           /* [*, ld_agg] or NULL */
+  int32_t ld_agg;
+  const int32_t* agg_index; /* [rows] destination of each output row */
+  int32_t* agg_fix;         /* [gnc_mlp_agg_fix_len()] destinations left to gnc_agg_fixup_f32 */
 } gnc_mlp_desc_t;
 
 /* 0 if gnc_mlp_forward_f32 can run this description, GNC_ERR_UNSUPPORTED otherwise
@@ -172,6 +187,13 @@ typedef struct gnc_mlp_desc {
 size_t gnc_sizeof_mlp_desc(void);
 int gnc_mlp_supported(const gnc_mlp_desc_t* desc /* host */);
 int gnc_mlp_forward_f32(const gnc_mlp_desc_t* desc /* host */, void* stream);
+/* fused aggregation epilogue: 0 if this description can run with agg_out set (shape fields only) */
+int gnc_mlp_agg_supported(const gnc_mlp_desc_t* desc /* host */);
+int gnc_mlp_agg_fix_len(void); /* entries of agg_fix (2 per wave of the persistent grid) */
+/* out[v, :] = sum over k in [rowptr[v], rowptr[v+1]) of src[k, :] (ascending k) for the n_fix destinations
+ * v = fix[j] (entries < 0 or >= num_nodes are skipped; duplicates are harmless). */
+int gnc_agg_fixup_f32(const float* src, int64_t ld_src, const int32_t* rowptr, const int32_t* fix, int32_t n_fix,
+                      int64_t num_nodes, int32_t feat_dim, float* out, int64_t ld_out, void* stream);
 
 /* ---- K8: backward of the fused MLP ---------------------------------------------------------
  * Replaces what PyTorch's autograd does for `loss.backward()` (utils/train_model.py:41) through

@@ -266,6 +266,53 @@ def test_mlp_additive_segments_equal_concat_form(native, d):
     assert max_abs(y.cpu(), ref) < 1e-5
 
 
+@pytest.mark.parametrize("n,e,hot", [(211, 1500, 0), (40, 33, 0), (5000, 70001, 0), (3000, 90000, 30000), (7, 4096, 0)])
+def test_fused_aggregation_epilogue_bit_equals_k1(native, n, e, hot):
+    """the edge kernel's segmented-sum epilogue (gnc_mlp_desc_t.agg_out) + gnc_agg_fixup_f32 give,
+    bit for bit, what K1 gives on the stored rows: empty destinations, tails, more waves than tiles, one
+    destination spanning many waves' ranges (`hot` rows of destination 5)."""
+    d = 64
+    rng = np.random.default_rng(n + e)
+    sd = _mlp_sd(rng, 3 * d, d, d, 2, True)
+    dst = rng.integers(0, n, size=e)
+    if hot:
+        dst[:hot] = 5
+    if n > 20:
+        dst[dst == 11] = 12  # a destination without edges
+    dst = np.sort(dst).astype(np.int32)
+    src = rng.integers(0, n, size=e).astype(np.int32)
+    x = torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32)).to(DEV)
+    ea = torch.from_numpy(rng.standard_normal((e, d)).astype(np.float32)).to(DEV)
+    rowptr = torch.from_numpy(np.concatenate([[0], np.cumsum(np.bincount(dst, minlength=n))]).astype(np.int32)).to(DEV)
+    w0 = sd["m.model.0.weight"].to(DEV)
+    ws = [w0[:, 2 * d:], sd["m.model.2.weight"].to(DEV), sd["m.model.4.weight"].to(DEV)]
+    bs = [sd[f"m.model.{i}.bias"].to(DEV) for i in (0, 2, 4)]
+    ln = (sd["m.model.5.weight"].to(DEV), sd["m.model.5.bias"].to(DEV), 1e-5)
+    ps = native.mlp_forward([(x, None)], [w0[:, :d]], [None])
+    pd = native.mlp_forward([(x, None)], [w0[:, d:2 * d]], [None])
+    segs = [(ps, torch.from_numpy(src).to(DEV)), (pd, torch.from_numpy(dst).to(DEV)), (ea, None)]
+    modes = [native.SEG_ADD, native.SEG_ADD, native.SEG_MATMUL]
+    y0 = native.mlp_forward(segs, ws, bs, ln=ln, residual=ea, modes=modes)
+    y, agg = native.mlp_forward(segs, ws, bs, ln=ln, residual=ea, modes=modes,
+                                aggregate=(torch.from_numpy(dst).to(DEV), rowptr, n))
+    assert agg is not None, "the W-split edge shape at width 64 must take the fused epilogue"
+    assert torch.equal(y, y0)
+    ref = native.scatter_sum_csr(y, rowptr, None, n)
+    assert torch.equal(agg, ref)
+    # and the oracle's index_add_ order, for completeness
+    assert torch.equal(agg.cpu(), O.scatter_sum(y.cpu(), torch.from_numpy(dst).long(), dim_size=n))
+
+
+def test_fused_aggregation_falls_back_when_the_shape_cannot_carry_it(native):
+    rng = np.random.default_rng(5)
+    x = torch.from_numpy(rng.standard_normal((100, 128)).astype(np.float32)).to(DEV)
+    w = torch.from_numpy(rng.standard_normal((128, 128)).astype(np.float32)).to(DEV)
+    dst = torch.arange(100, dtype=torch.int32, device=DEV)
+    rowptr = torch.arange(101, dtype=torch.int32, device=DEV)
+    y, agg = native.mlp_forward([(x, None)], [w], [None], aggregate=(dst, rowptr, 100))
+    assert agg is None and max_abs(y.cpu(), x.cpu() @ w.cpu().t()) < 1e-4
+
+
 def test_gather_window_id_outside_the_stated_table_reads_zero(native):
     """gnc_mlp_segment_t.table_rows: the weights-resident kernel gathers through a bounds-checked buffer window,
     so an id at or beyond the stated table reads zeros.  The table is the first half of a larger allocation, so a

@@ -184,6 +184,24 @@ def test_forward_batched_variable_size_readout_policy(G):
             assert max_abs(lb[gi], ref) < 2e-6
 
 
+def test_fused_aggregation_forward_is_bit_identical_to_separate_k1(G, monkeypatch):
+    """under no_grad the edge launch forms the node model's aggregate in its epilogue; the forward
+    must not change by a single bit against the path with K1 as a separate launch."""
+    from graphnet_classifier_amd import synthetic as S
+    batch, kw = S.make_workload("c3", scale=0.01)
+    torch.manual_seed(11)
+    m = G.GraphNet(**kw)
+    with torch.no_grad():
+        monkeypatch.setattr(G, "FUSED_AGG", True)
+        y1 = m(batch.x, batch.pos, batch.edge_index)
+        monkeypatch.setattr(G, "FUSED_AGG", False)
+        y0 = m(batch.x, batch.pos, batch.edge_index)
+    assert torch.equal(y0, y1)
+    # with autograd on the separate, differentiable K1 is used and gives the same values
+    y2 = m(batch.x, batch.pos, batch.edge_index)
+    assert y2.requires_grad and torch.equal(y2.detach(), y0)
+
+
 def test_edge_order_invariance(G):
     """Permuting the edge list changes only the per-destination summation order (fp32 noise)."""
     from graphnet_classifier_amd import synthetic as S
