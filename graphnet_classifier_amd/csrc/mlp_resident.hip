@@ -299,6 +299,11 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
       prv = lane == 0 ? agg_cur : prv;
       const unsigned long long vmask = valid >= 32 ? 0xffffffffull : ((1ull << valid) - 1ull);
       const unsigned long long bnd = __ballot(aid != prv) & vmask;
+      // all 32 row values first (one batch of LDS reads): the walk below has a scalar branch per row, and a
+      // read inside it would cost a full LDS round trip every time
+      float rowv[RPW];
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) rowv[r] = abuf[r * LDSW + lane];
 #pragma unroll
       for (int r = 0; r < RPW; ++r) {
         if (r < valid) {
@@ -315,7 +320,7 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
             agg_cur = __builtin_amdgcn_readlane(aid, r);
             agg_acc = 0.f;
           }
-          agg_acc += abuf[r * LDSW + lane];
+          agg_acc += rowv[r];
         }
       }
       aid = aid_next;

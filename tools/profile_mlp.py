@@ -36,6 +36,14 @@ for it in range(iters):
         pd = native.mlp_forward([(x, None)], [w0[:, d:2 * d]], [None])
         y = native.mlp_forward([(ps, src), (pd, dst), (ea, None)], [w0[:, 2 * d:], w1, w2], [b0, b1, b2], ln=ln,
                                residual=ea, modes=[1, 1, 0])
+    elif mode == "wsplit_agg":  # the same launch with the fused aggregation epilogue (dst is sorted above)
+        ps = native.mlp_forward([(x, None)], [w0[:, :d]], [None])
+        pd = native.mlp_forward([(x, None)], [w0[:, d:2 * d]], [None])
+        if it == 0:
+            rowptr = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev),
+                                torch.cumsum(torch.bincount(dst.long(), minlength=n), 0)]).int()
+        y, agg = native.mlp_forward([(ps, src), (pd, dst), (ea, None)], [w0[:, 2 * d:], w1, w2], [b0, b1, b2], ln=ln,
+                                    residual=ea, modes=[1, 1, 0], aggregate=(dst, rowptr, n))
     elif mode == "concat":
         y = native.mlp_forward([(x, src), (x, dst), (ea, None)], [w0, w1, w2], [b0, b1, b2], ln=ln, residual=ea)
     elif mode == "enc":
