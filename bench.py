@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--preheat-ms", type=float, default=600.0, help="untimed device pre-heat before the warm-up steps")
     ap.add_argument("--workload", default="c3", choices=sorted(synthetic.WORKLOADS))
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -179,8 +180,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # warm-up steps run exactly like timed ones (per-launch HIP events included), so that nothing - event pools,
+    # allocator blocks, lazily loaded code objects - is created for the first time inside the timed region
+    native.set_kernel_timers(native.KernelTimers())
+    # device pre-heat (untimed, before the W warm-up steps): on a cold box the first ~0.1-0.3 s of sustained load
+    # contain one 40-60 ms stall (seen on every fresh MI355X box, in whichever step falls there), presumably
+    # the power controller settling; it must not land in the K timed steps
+    if a.preheat_ms > 0:
+        t_heat = time.perf_counter()
+        y = step()
+        torch.cuda.synchronize()
+        one = max((time.perf_counter() - t_heat) * 1e3, 1e-3)
+        n_heat = torch.tensor([min(200, int(a.preheat_ms / one) + 1)], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+        if world > 1:  # the training step contains a collective: every rank must run the same number of steps
+            dist.all_reduce(n_heat, op=dist.ReduceOp.MAX)
+        for _ in range(int(n_heat.item())):
+            y = step()
+        torch.cuda.synchronize()
     for _ in range(a.warmup):
         y = step()
+        torch.cuda.Event(enable_timing=True).record()
     timers = native.KernelTimers()
     native.set_kernel_timers(timers)
     fence()
@@ -192,7 +211,8 @@ def main():
         marks[k + 1].record()
     fence()
     elapsed = time.perf_counter() - t0
-    per_step = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(a.steps))
+    per_step_order = [marks[k].elapsed_time(marks[k + 1]) for k in range(a.steps)]
+    per_step = sorted(per_step_order)
     # (not part of `value`) the same step with the topology cached: SURVEY 8d asks for the throughput with and
     # without the CSR build
     cached_ms = None
@@ -276,7 +296,8 @@ def main():
                              # the reference's concat form of the same launch (W-split removes 2 of the 3 first-Linear blocks)
                              "reference_form_flops_per_launch": mlp["avg_work"] + (4.0 * batch.num_edges * w["width"] ** 2
                                                                                     if "+2add" in mlp_name else 0.0)},
-            "step_ms_spread": {"min": per_step[0], "median": per_step[len(per_step) // 2], "max": per_step[-1]},
+            "step_ms_spread": {"min": per_step[0], "median": per_step[len(per_step) // 2], "max": per_step[-1],
+                               "slowest_step": per_step_order.index(per_step[-1])},
             "kernel_ms_per_step": {k: v["avg_ms"] * v["launches"] / a.steps for k, v in ksum.items()
                                    if not (k1_isolated and k.startswith("scatter_sum_csr"))},
         }

@@ -304,23 +304,33 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
       float rowv[RPW];
 #pragma unroll
       for (int r = 0; r < RPW; ++r) rowv[r] = abuf[r * LDSW + lane];
-#pragma unroll
-      for (int r = 0; r < RPW; ++r) {
-        if (r < valid) {
-          if ((bnd >> r) & 1ull) {
-            if (agg_cur >= 0) {
-              if (agg_first) {  // the range's first destination may have begun in the previous range: fix-up's
-                agg_first = false;
-                agg_first_dst = agg_cur;
-              } else if (lane < out_dim) {
-                float* dstp = d.agg_out + (int64_t)agg_cur * d.ld_agg;
-                asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2\n\ts_nop 0" ::"v"(lane * 4), "v"(agg_acc), "s"(dstp) : "memory");
-              }
+      auto agg_row = [&](int r) {  // r and everything tested here are wave-uniform
+        if ((bnd >> r) & 1ull) {
+          if (agg_cur >= 0) {
+            if (agg_first) {  // the range's first destination may have begun in the previous range: fix-up's
+              agg_first = false;
+              agg_first_dst = agg_cur;
+            } else if (lane < out_dim) {
+              float* dstp = d.agg_out + (int64_t)agg_cur * d.ld_agg;
+              asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2\n\ts_nop 0" ::"v"(lane * 4), "v"(agg_acc), "s"(dstp) : "memory");
             }
-            agg_cur = __builtin_amdgcn_readlane(aid, r);
-            agg_acc = 0.f;
           }
-          agg_acc += rowv[r];
+          agg_cur = __builtin_amdgcn_readlane(aid, r);
+          agg_acc = 0.f;
+        }
+        agg_acc += rowv[r];
+      };
+#pragma unroll
+      for (int r4 = 0; r4 < RPW; r4 += 4) {
+        if (r4 + 4 <= valid && ((bnd >> r4) & 0xfull) == 0) {  // four rows of the destination in progress: no tests
+          agg_acc += rowv[r4 + 0];
+          agg_acc += rowv[r4 + 1];
+          agg_acc += rowv[r4 + 2];
+          agg_acc += rowv[r4 + 3];
+        } else {
+#pragma unroll
+          for (int r = r4; r < r4 + 4; ++r)
+            if (r < valid) agg_row(r);
         }
       }
       aid = aid_next;
