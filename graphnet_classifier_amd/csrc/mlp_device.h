@@ -486,6 +486,22 @@ __device__ __forceinline__ void hidden_window_store(f32x4 v, uint32_t byte_off, 
       : "memory");
 }
 
+// Descriptor for a FULL tile (every row inside the table), as cheap as it gets: below 4 GiB a window over the
+// whole table - loop-invariant, no per-tile 64-bit arithmetic - plus the tile's first row as a 32-bit byte offset
+// for the caller's lane offset (one s_mul + one v_add per tile); larger tables get a window at the tile's first
+// row.  Every instruction of a wave that is not an MFMA crawls at ~1 per 37 cycles while its SIMD mate streams
+// MFMAs (tools/hw_probe.hip), so the scalar instructions of the tile loop count like vector ones.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t full_tile_window(const float* base, int64_t row0, int64_t rows, int ld,
+                                                                   uint32_t* row0_bytes) {
+  const int64_t tbytes = rows * (int64_t)ld * 4;
+  if (tbytes <= 0xffffffffll) {
+    *row0_bytes = (uint32_t)row0 * (uint32_t)(ld * 4);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)(uint32_t)tbytes, 0x00020000);
+  }
+  *row0_bytes = 0;
+  return row_window(base, row0, rows, ld);
+}
+
 // A tile's eight 4-row pieces through windows.  Full tiles: ONE window, the piece offset rides in the
 // instruction's SGPR offset (1 SALU per piece, no VGPR, but that field is not bounds-checked).  The last tile
 // and anything beyond the table: one window per piece, so the bounds check sees the row.
@@ -494,10 +510,12 @@ __device__ __forceinline__ void load_tile_rows(f32x4 (&pre)[PIECES], const float
                                                uint32_t lane_off) {
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   if (row0 + 4 * PIECES <= rows) {
-    const __amdgpu_buffer_rsrc_t w = row_window(base, row0, rows, ld);
+    uint32_t r0b;
+    const __amdgpu_buffer_rsrc_t w = full_tile_window(base, row0, rows, ld, &r0b);
+    const uint32_t voff = lane_off + r0b;
 #pragma unroll
     for (int p = 0; p < PIECES; ++p)
-      pre[p] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(w, lane_off, p * 16 * ld, STREAM ? 2 : 0));
+      pre[p] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(w, voff, p * 16 * ld, STREAM ? 2 : 0));
   } else {
 #pragma unroll
     for (int p = 0; p < PIECES; ++p)
@@ -537,10 +555,11 @@ __device__ __forceinline__ void store_staged_rows(const float* abuf, float* dst,
       const uint32_t off = (uint32_t)(rs * ld + col) * 4u;
       if (col < width) {
         if (row0 + 4 * PIECES <= rows) {
-          const __amdgpu_buffer_rsrc_t w = row_window(dst, row0, rows, ld);
+          uint32_t r0b;
+          const __amdgpu_buffer_rsrc_t w = full_tile_window(dst, row0, rows, ld, &r0b);
 #pragma unroll
           for (int p = 0; p < PIECES; ++p)
-            hidden_window_store_s(v[p] + *reinterpret_cast<const f32x4*>(src + p * 4 * LDSW), off, w, (uint32_t)(p * 16 * ld));
+            hidden_window_store_s(v[p] + *reinterpret_cast<const f32x4*>(src + p * 4 * LDSW), off + r0b, w, (uint32_t)(p * 16 * ld));
         } else {
 #pragma unroll
           for (int p = 0; p < PIECES; ++p)
@@ -561,10 +580,11 @@ __device__ __forceinline__ void store_staged_rows(const float* abuf, float* dst,
     const uint32_t off = (uint32_t)(rs * ld + col) * 4u;
     if (col < width) {
       if (row0 + 4 * PIECES <= rows) {
-        const __amdgpu_buffer_rsrc_t w = row_window(dst, row0, rows, ld);
+        uint32_t r0b;
+        const __amdgpu_buffer_rsrc_t w = full_tile_window(dst, row0, rows, ld, &r0b);
 #pragma unroll
         for (int p = 0; p < PIECES; ++p)
-          hidden_window_store_s(*reinterpret_cast<const f32x4*>(src + p * 4 * LDSW), off, w, (uint32_t)(p * 16 * ld));
+          hidden_window_store_s(*reinterpret_cast<const f32x4*>(src + p * 4 * LDSW), off + r0b, w, (uint32_t)(p * 16 * ld));
       } else {
 #pragma unroll
         for (int p = 0; p < PIECES; ++p)

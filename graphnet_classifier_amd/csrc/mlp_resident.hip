@@ -233,6 +233,7 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
           off0 = row_offset(nwt + stride, sv[0]);
         }
       }
+      PROBE(7);  // issue of the next rows' loads
       mma_chunk_from_lds<HT>(hid, abuf, wres + s * CH, (sv[s].width + 7) >> 3, i, h);
       if constexpr (RESREG) if (s == NMM - 1) {
 #pragma unroll
@@ -340,6 +341,12 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
     // no later wait for them has to sit out the stores as well.
 #pragma unroll
     for (int p = 0; p < NP; ++p) asm volatile("" ::"v"(cur[p]));
+    // ... and the gather ids fetched for the next tile: their first use comes after the stores, where a wait for
+    // them (vmcnt is in order) would sit out the stores' HBM round trip
+#pragma unroll
+    for (int s = 1; s < NS; ++s) asm volatile("" ::"v"(offs[s]));
+    asm volatile("" ::"v"(off0));
+    if constexpr (AGG) asm volatile("" ::"v"(aid_next));
 
     // ------------------------------------------------------------------ epilogue: whole rows out
     {
@@ -355,9 +362,10 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
       if (vec_out) {  // rows past the end are dropped by the window's bounds check
         if (col_out < out_dim) {
           if (row0 + RPW <= rows) {
-            const __amdgpu_buffer_rsrc_t ow = row_window(d.out, row0, rows, d.ld_out);
+            uint32_t r0b;
+            const __amdgpu_buffer_rsrc_t ow = full_tile_window(d.out, row0, rows, d.ld_out, &r0b);
 #pragma unroll
-            for (int p = 0; p < NP; ++p) hidden_window_store_s(outv[p], out_lane_off, ow, (uint32_t)(p * 16 * d.ld_out));
+            for (int p = 0; p < NP; ++p) hidden_window_store_s(outv[p], out_lane_off + r0b, ow, (uint32_t)(p * 16 * d.ld_out));
           } else {
 #pragma unroll
             for (int p = 0; p < NP; ++p) hidden_window_store(outv[p], out_lane_off, row_window(d.out, row0 + 4 * p, rows, d.ld_out));

@@ -68,7 +68,7 @@ if hasattr(lib, "gnc_phase_probe_read"):
     lib.gnc_phase_probe_read(buf.ctypes.data, buf.nbytes)
     b = buf.reshape(2048, 12).astype(np.float64)
     tiles = (e + 31) // 32 / 2048
-    names = ["wait+stage", "L0 mfma", "add step", "hidden", "last", "LN+transpose", "epilogue"]
-    print("cycles per tile and wave:", {n: round(v / tiles) for n, v in zip(names, b[:, :7].mean(0))},
+    names = ["wait+stage", "L0 mfma", "add step", "hidden", "last", "LN+transpose", "epilogue", "load issue"]
+    print("cycles per tile and wave:", {n: round(v / tiles) for n, v in zip(names, b[:, :8].mean(0))},
           "total", round(b[:, 8].mean() / tiles))
     print("shader clock GHz during the kernel:", round(float((b[:, 8] / b[:, 9]).mean()) * 0.1, 3))
