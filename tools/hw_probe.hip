@@ -86,6 +86,12 @@ __global__ __launch_bounds__(512) void coissue(float* out, unsigned long long* c
         x2 = __builtin_fmaf(x2, a0, 1.f); x3 = __builtin_fmaf(x3, a0, 1.f);
       }
     s = x0 + x1 + x2 + x3;
+  } else if (mode == 2) {  // scalar-ALU mate: 64 dependent s_add_u32 per iteration
+    unsigned acc = (unsigned)mfma_iters;
+    for (int it = 0; it < valu_iters; ++it)
+#pragma unroll
+      for (int k = 0; k < 64; ++k) asm volatile("s_add_u32 %0, %0, 3" : "+s"(acc));
+    s = (float)acc;
   } else {
     f32x4 x = {0.f, 0.f, 0.f, 0.f};
     const f32x4* p = reinterpret_cast<const f32x4*>(lds) + (threadIdx.x & 63);
@@ -155,8 +161,8 @@ static void run_coissue(int mfma_iters, int valu_iters, int mode) {
   const double mf = mfma_iters ? (double)h[0] / (mfma_iters * 16.0) : 0.0;
   const double va = valu_iters ? (double)h[4] / (valu_iters * 64.0) : 0.0;
   printf("{\"probe\": \"coissue\", \"flags\": %d, \"mate\": \"%s\", \"mfma_iters\": %d, \"mate_iters\": %d, \"cycles_per_mfma\": %.1f, "
-         "\"cycles_per_mate_instr\": %.2f}\n", mode >> 4, (mode & 15) == 0 ? "v_fma_f32" : "ds_read_b128+4 v_add", mfma_iters, valu_iters, mf,
-         (mode & 15) == 0 ? va : va * 4.0);
+         "\"cycles_per_mate_instr\": %.2f}\n", mode >> 4, (mode & 15) == 0 ? "v_fma_f32" : (mode & 15) == 2 ? "s_add_u32" : "ds_read_b128+4 v_add", mfma_iters, valu_iters, mf,
+         (mode & 15) == 1 ? va * 4.0 : va);
   hipFree(out);
   hipFree(cyc);
 }
@@ -265,6 +271,8 @@ int main(int argc, char** argv) {
   run_coissue(20000, 20000, 0);
   run_coissue(0, 20000, 1);
   run_coissue(20000, 20000, 1);
+  run_coissue(0, 20000, 2);                  // scalar ALU alone
+  run_coissue(20000, 20000, 2);              // scalar ALU next to an MFMA stream
   run_coissue(20000, 20000, 0 | (1 << 4));   // MFMA mate with 4 independent accumulators
   run_coissue(20000, 20000, 0 | (2 << 4));   // VALU wave at s_setprio 3
   run_coissue(20000, 20000, 0 | (3 << 4));
