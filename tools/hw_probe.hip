@@ -90,7 +90,7 @@ __global__ __launch_bounds__(512) void coissue(float* out, unsigned long long* c
     unsigned acc = (unsigned)mfma_iters;
     for (int it = 0; it < valu_iters; ++it)
 #pragma unroll
-      for (int k = 0; k < 64; ++k) asm volatile("s_add_u32 %0, %0, 3" : "+s"(acc));
+      for (int k = 0; k < 64; ++k) asm volatile("s_add_u32 %0, %0, 3" : "+s"(acc) :: "memory");
     s = (float)acc;
   } else {
     f32x4 x = {0.f, 0.f, 0.f, 0.f};
@@ -107,6 +107,62 @@ __global__ __launch_bounds__(512) void coissue(float* out, unsigned long long* c
 
 // Same-wave interleave: after every MFMA of a dependent chain, KV independent v_fma_f32 (4 chains).  Shows how
 // many VALU instructions fit in the shadow of one 64-cycle MFMA when they come from the SAME wave.
+// Same question for instructions that do not use the vector ALU: KS scalar adds, or KS LDS reads, after every MFMA
+// of the same wave.
+template <int KS, bool LDSR>
+__global__ __launch_bounds__(256) void interleave_other(float* out, unsigned long long* cyc, int iters, float a0) {
+  __shared__ float lds[1024];
+  for (int k = threadIdx.x; k < 1024; k += blockDim.x) lds[k] = a0 * k;
+  __syncthreads();
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float a = a0 + threadIdx.x * 1e-6f;
+  unsigned sacc = (unsigned)iters;
+  float lv[KS > 0 ? KS : 1];
+#pragma unroll
+  for (int v = 0; v < KS; ++v) lv[v] = 0.f;
+  const unsigned laddr = (threadIdx.x & 63) * 4;
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(a0));
+#pragma unroll
+      for (int v = 0; v < KS; ++v) {
+        if (LDSR) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(lv[v]) : "v"(laddr), "n"(v * 256));
+        else asm volatile("s_add_u32 %0, %0, 3" : "+s"(sacc) :: "memory");
+      }
+    }
+    if (LDSR) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  float s = (float)sacc;
+#pragma unroll
+  for (int v = 0; v < KS; ++v) s += lv[v];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s += acc[r];
+  if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) cyc[threadIdx.x >> 6] = t1 - t0;
+  if (s == 123.456f) out[0] = s;
+}
+
+template <int KS, bool LDSR>
+static void run_interleave_other(int iters) {
+  float* out;
+  unsigned long long *cyc, h[8];
+  hipMalloc(&out, 4);
+  hipMalloc(&cyc, 64);
+  interleave_other<KS, LDSR><<<256, 256>>>(out, cyc, iters, 1e-3f);
+  hipDeviceSynchronize();
+  interleave_other<KS, LDSR><<<256, 256>>>(out, cyc, iters, 1e-3f);
+  hipDeviceSynchronize();
+  hipMemcpy(h, cyc, 64, hipMemcpyDeviceToHost);
+  printf("{\"probe\": \"interleave\", \"waves_per_simd\": 1, \"%s_per_mfma\": %d, \"cycles_per_mfma_slot\": %.1f}\n",
+         LDSR ? "ds_read_b32" : "s_add_u32", KS, (double)h[0] / (iters * 8.0));
+  hipFree(out);
+  hipFree(cyc);
+}
+
 template <int KV>
 __global__ __launch_bounds__(512) void interleave(float* out, unsigned long long* cyc, int iters, float a0) {
   f32x16 acc;
@@ -285,6 +341,9 @@ int main(int argc, char** argv) {
   run_interleave<8>(20000, 8);
   run_interleave<12>(20000, 8);
   run_interleave<16>(20000, 8);
+  run_interleave_other<2, true>(20000);
+  run_interleave_other<4, true>(20000);
+  run_interleave_other<8, true>(20000);
   const size_t bytes = 2560000000ull;
   run_read<4, false>(bytes, 8);
   run_read<4, true>(bytes, 8);
