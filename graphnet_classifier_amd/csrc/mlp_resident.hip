@@ -365,7 +365,7 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
             uint32_t r0b;
             const __amdgpu_buffer_rsrc_t ow = full_tile_window(d.out, row0, rows, d.ld_out, &r0b);
 #pragma unroll
-            for (int p = 0; p < NP; ++p) hidden_window_store_s(outv[p], out_lane_off + r0b, ow, (uint32_t)(p * 16 * d.ld_out));
+            for (int p = 0; p < NP; ++p) hidden_window_store_s<true>(outv[p], out_lane_off + r0b, ow, (uint32_t)(p * 16 * d.ld_out));
           } else {
 #pragma unroll
             for (int p = 0; p < NP; ++p) hidden_window_store(outv[p], out_lane_off, row_window(d.out, row0 + 4 * p, rows, d.ld_out));

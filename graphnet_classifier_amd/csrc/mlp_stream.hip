@@ -325,7 +325,7 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_stream_kernel(const gnc_mlp_de
           default: chunk_to_lds<OT, 6>(o, abuf, i, h); break;
         }
         compiler_lds_barrier();
-        store_staged_rows(abuf, d.out + cc * KC, d.ld_out, out_dim - cc * KC < KC ? out_dim - cc * KC : KC, row0, rows, c4, rs,
+        store_staged_rows<NP, true>(abuf, d.out + cc * KC, d.ld_out, out_dim - cc * KC < KC ? out_dim - cc * KC : KC, row0, rows, c4, rs,
                           d.residual ? d.residual + cc * KC : nullptr, d.ld_residual);
       }
     }

@@ -394,7 +394,7 @@ __global__ __launch_bounds__(NT16) void mlp_stream16_kernel(const gnc_mlp_desc_t
         for (int cb = 0; cb < 4; ++cb)
           if (4 * cc + cb < NTO) *reinterpret_cast<f32x4*>(abuf + i * LDSW + 16 * cb + 4 * g) = o[4 * cc + cb < NTO ? 4 * cc + cb : 0];
         compiler_lds_barrier();
-        store_staged_rows<NP16>(abuf, d.out + cc * KC, d.ld_out, out_dim - cc * KC < KC ? out_dim - cc * KC : KC, row0, rows, c4,
+        store_staged_rows<NP16, true>(abuf, d.out + cc * KC, d.ld_out, out_dim - cc * KC < KC ? out_dim - cc * KC : KC, row0, rows, c4,
                                 rs, d.residual ? d.residual + cc * KC : nullptr, d.ld_residual);
       }
     }
