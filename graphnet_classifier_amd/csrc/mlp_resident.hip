@@ -216,6 +216,7 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
     init_bias<HT>(hid, pbuf, h);
 #pragma unroll
     for (int s = 0; s < NMM; ++s) {
+      bool interleaved = false;
       stage(cur, sv[s].width);
       PROBE(0);  // wait for the step's rows + staging
       // request what comes next before the MFMAs of this step start
@@ -224,17 +225,54 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
         offs[s + 1 < NMM ? s + 1 : 0] = row_offset(nwt, sv[s + 1 < NMM ? s + 1 : 0]);
       } else {
         if constexpr (NADD > 0) {
-          load_rows(addA, sv[NMM], wt, offs[NMM]);
-          load_rows(addB, sv[NMM + 1], wt, offs[NMM + 1]);
-          offs[NMM] = row_offset(nwt, sv[NMM]);
-          offs[NMM + 1] = row_offset(nwt, sv[NMM + 1]);
+          if (sv[s].width == KC && sv[NMM].index && sv[NMM + 1].index) {
+            // Gathered ADD rows requested from INSIDE the first Linear's MFMA loop: LDS / VMEM / scalar
+            // instructions of a wave ride in the shadow of its own MFMAs (tools/hw_probe.hip: up to ~4 per MFMA for
+            // free), whereas issued in front of the loop they crawl at ~1 per 37 cycles whenever the SIMD mate
+            // is streaming MFMAs.  One 4-row piece of each table per k-group; the row offsets travel one group
+            // ahead by ds_bpermute.
+            const SegView &sa = sv[NMM], &sb = sv[NMM + 1];
+            const __amdgpu_buffer_rsrc_t wa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sa.ptr), 0, (int)sa.bytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t wb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sb.ptr), 0, (int)sb.bytes, 0x00020000);
+            const uint32_t cola = (uint32_t)(c4 * 4 < sa.ld ? c4 * 16 : 0), colb = (uint32_t)(c4 * 4 < sb.ld ? c4 * 16 : 0);
+            const int rba = (int)(offs[NMM] * (uint32_t)(sa.ld * 4)), rbb = (int)(offs[NMM + 1] * (uint32_t)(sb.ld * 4));
+            int na = __shfl(rba, rs, 64), nb = __shfl(rbb, rs, 64);
+            const float* wch = wres + s * CH;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+              const f32x4 b = *reinterpret_cast<const f32x4*>(abuf + i * LDSW + 8 * g + 4 * h);
+#pragma unroll
+              for (int t = 0; t < HT; ++t) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(wch + (32 * t + i) * LDSW + 8 * g + 4 * h);
+                hid[t] = mfma(a.x, b.x, hid[t]);
+                hid[t] = mfma(a.y, b.y, hid[t]);
+                hid[t] = mfma(a.z, b.z, hid[t]);
+                hid[t] = mfma(a.w, b.w, hid[t]);
+              }
+              const uint32_t oa = (uint32_t)na + cola, ob = (uint32_t)nb + colb;
+              if (g + 1 < 8) {
+                na = __shfl(rba, (g + 1) * 4 + rs, 64);
+                nb = __shfl(rbb, (g + 1) * 4 + rs, 64);
+              }
+              addA[g] = window_load(wa, oa);
+              addB[g] = window_load(wb, ob);
+            }
+            offs[NMM] = row_offset(nwt, sv[NMM]);
+            offs[NMM + 1] = row_offset(nwt, sv[NMM + 1]);
+            interleaved = true;
+          } else {
+            load_rows(addA, sv[NMM], wt, offs[NMM]);
+            load_rows(addB, sv[NMM + 1], wt, offs[NMM + 1]);
+            offs[NMM] = row_offset(nwt, sv[NMM]);
+            offs[NMM + 1] = row_offset(nwt, sv[NMM + 1]);
+          }
         } else {
           load_rows(cur, sv[0], nwt, off0);
           off0 = row_offset(nwt + stride, sv[0]);
         }
       }
       PROBE(7);  // issue of the next rows' loads
-      mma_chunk_from_lds<HT>(hid, abuf, wres + s * CH, (sv[s].width + 7) >> 3, i, h);
+      if (!interleaved) mma_chunk_from_lds<HT>(hid, abuf, wres + s * CH, (sv[s].width + 7) >> 3, i, h);
       if constexpr (RESREG) if (s == NMM - 1) {
 #pragma unroll
         for (int t = 0; t < HT; ++t)
