@@ -97,8 +97,8 @@ def cpu_baseline(batch, kw, n_blocks, target_seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--preheat-ms", type=float, default=600.0, help="untimed device pre-heat before the warm-up steps")
     ap.add_argument("--workload", default="c3", choices=sorted(synthetic.WORKLOADS))
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
