@@ -57,6 +57,20 @@ __global__ void permute_index_i64_i32(const int64_t* __restrict__ src, const int
   for (; i < n; i += stride) out[i] = (int32_t)src[perm ? perm[i] : i];
 }
 
+__global__ void permute_index_checked_i64_i32(const int64_t* __restrict__ src, const int32_t* __restrict__ perm, int64_t n,
+                                              int64_t num_nodes, int32_t* __restrict__ out, int32_t* __restrict__ status) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  bool bad = false;
+  for (; i < n; i += stride) {
+    const int64_t v = src[perm ? perm[i] : i];
+    const bool ok = v >= 0 && v < num_nodes;
+    bad |= !ok;
+    out[i] = ok ? (int32_t)v : 0;
+  }
+  if (bad) *status = 1;  // every writer stores the same value
+}
+
 unsigned key_bits(int64_t num_nodes) {  // bits needed to represent the sentinel value num_nodes
   unsigned b = 1;
   while (b < 32 && ((uint64_t)num_nodes >> b) != 0) ++b;
@@ -137,6 +151,15 @@ extern "C" int gnc_csr_build(const int64_t* index, int64_t num_edges, int64_t nu
   if (rc) return rc;
   csr_rowptr_from_sorted<<<grid_for(num_edges + 1), gnc::kBlock, 0, stream>>>(keys_out, num_edges, num_nodes, rowptr);
   return gnc::check_launch("csr_rowptr_from_sorted");
+}
+
+extern "C" int gnc_permute_index_checked_i64_i32(const int64_t* src, const int32_t* perm, int64_t n, int64_t num_nodes,
+                                                 int32_t* out, int32_t* status, void* stream_) {
+  GNC_REQUIRE(n >= 0 && num_nodes >= 0, "gnc_permute_index_checked_i64_i32: negative size");
+  if (n == 0) return GNC_OK;
+  GNC_REQUIRE(src && out && status, "gnc_permute_index_checked_i64_i32: null pointer");
+  permute_index_checked_i64_i32<<<grid_for(n), gnc::kBlock, 0, (hipStream_t)stream_>>>(src, perm, n, num_nodes, out, status);
+  return gnc::check_launch("permute_index_checked_i64_i32");
 }
 
 extern "C" int gnc_permute_index_i64_i32(const int64_t* src, const int32_t* perm, int64_t n, int32_t* out,

@@ -36,6 +36,7 @@ _SIGNATURES = {
     "gnc_csr_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "gnc_csr_build": (c_int32, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "gnc_permute_index_i64_i32": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "gnc_permute_index_checked_i64_i32": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "gnc_scatter_sum_csr_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p,
                                           c_int64, c_void_p]),
     "gnc_gather_rows_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p]),
@@ -197,7 +198,7 @@ def _launch(name: str, t: torch.Tensor, fn, work: float = 0.0):
 
 # --------------------------------------------------------------------------- topology
 def csr_build(index: torch.Tensor, num_nodes: int):
-    """index [E] int64 (device) -> (rowptr int32 [N+1], perm int32 [E], status int32 [1])."""
+    """index [E] int64 (device) -> (rowptr int32 [N+1], perm int32 [E], status int32 [2]: [0] = out-of-range flag of the build, [1] = scratch flag for a checked permute)."""
     lib = load_library()
     _require_cuda(index)
     if index.dtype != torch.int64:
@@ -207,7 +208,7 @@ def csr_build(index: torch.Tensor, num_nodes: int):
     dev = index.device
     rowptr = torch.empty(num_nodes + 1, dtype=torch.int32, device=dev)
     perm = torch.empty(e, dtype=torch.int32, device=dev)
-    status = torch.empty(1, dtype=torch.int32, device=dev)
+    status = torch.zeros(2, dtype=torch.int32, device=dev)  # [0]: written by the build, [1]: free for a checked permute
     with torch.cuda.device(dev):
         nbytes = lib.gnc_csr_workspace_bytes(num_nodes, e)
         if nbytes == 0:
@@ -216,6 +217,20 @@ def csr_build(index: torch.Tensor, num_nodes: int):
         _check(lib.gnc_csr_build(index.data_ptr(), e, num_nodes, rowptr.data_ptr(), perm.data_ptr(), status.data_ptr(),
                                  ws.data_ptr(), nbytes, _stream(index)), "gnc_csr_build")
     return rowptr, perm, status
+
+
+def permute_index_checked(src: torch.Tensor, perm: torch.Tensor | None, num_nodes: int, status: torch.Tensor) -> torch.Tensor:
+    """``permute_index`` that also flags ids outside [0, num_nodes) in ``status`` (int32 [1] on the device, zero
+    before the call) and stores them as 0."""
+    lib = load_library()
+    _require_cuda(src, status)
+    src = src.contiguous()
+    out = torch.empty(src.numel(), dtype=torch.int32, device=src.device)
+    with torch.cuda.device(src.device):
+        _check(lib.gnc_permute_index_checked_i64_i32(src.data_ptr(), perm.data_ptr() if perm is not None else None, src.numel(),
+                                                     num_nodes, out.data_ptr(), status.data_ptr(), _stream(src)),
+               "gnc_permute_index_checked_i64_i32")
+    return out
 
 
 def permute_index(src: torch.Tensor, perm: torch.Tensor | None) -> torch.Tensor:

@@ -40,7 +40,7 @@ class GraphTopology:
         self.device = device
         row, col = ei[0].contiguous(), ei[1].contiguous()
         self.rowptr, self.perm, status = native.csr_build(col, self.num_nodes)
-        self.src_sorted = native.permute_index(row, self.perm)
+        self.src_sorted = native.permute_index_checked(row, self.perm, self.num_nodes, status[1:])
         self.dst_sorted = native.permute_index(col, self.perm)
         self._row, self._col = row, col  # int32 copies in ORIGINAL edge order are built on first use
         self._row32 = None
@@ -50,8 +50,7 @@ class GraphTopology:
         if validate:
             # one host sync per topology build; the reference syncs on every scatter
             # (models/GNN.py:16-17 `index.max().item()`) and raises IndexError for a bad index
-            bad_dst = int(status.item())
-            bad_src = bool(((row < 0) | (row >= self.num_nodes)).any().item()) if self.num_edges else False
+            bad_dst, bad_src = status.tolist()  # both flags, one sync
             if bad_dst or bad_src:
                 raise IndexError(f"edge_index has node ids outside [0, {self.num_nodes})")
 

@@ -73,6 +73,11 @@ int gnc_csr_build(const int64_t* index, int64_t num_edges, int64_t num_nodes,
 
 /* out[k] = (int32) src[perm[k]]   -- narrows and reorders an int64 edge_index row. */
 int gnc_permute_index_i64_i32(const int64_t* src, const int32_t* perm, int64_t n, int32_t* out, void* stream);
+/* Same, and validates on the way: a value outside [0, num_nodes) sets *status (device int32, caller zero-fills)
+ * to 1 and is stored as 0, so that nothing downstream can index out of range before the host has looked at
+ * the flag (models/GNN.py:18-20: `index_add_` raises IndexError for such an id). */
+int gnc_permute_index_checked_i64_i32(const int64_t* src, const int32_t* perm, int64_t n, int64_t num_nodes, int32_t* out,
+                                      int32_t* status, void* stream);
 
 /* ---- K1: scatter-sum neighbourhood aggregation ------------------------------------------
  * Replaces `scatter_sum(edge_attr, col, dim=0)` (models/GNN.py:99 -> :11-21):

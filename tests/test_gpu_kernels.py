@@ -35,7 +35,7 @@ def test_csr_build_matches_stable_sort(native, n, e):
     rng = np.random.default_rng(n * 7 + e)
     index = _random_index(rng, n, e) if e else torch.zeros(0, dtype=torch.int64)
     rowptr, perm, status = native.csr_build(index.to(DEV), n)
-    assert int(status.item()) == 0
+    assert status.tolist() == [0, 0]
     order = np.argsort(index.numpy(), kind="stable")
     counts = np.bincount(index.numpy(), minlength=n)
     ref_rowptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
@@ -46,13 +46,24 @@ def test_csr_build_matches_stable_sort(native, n, e):
 def test_csr_build_flags_out_of_range(native):
     index = torch.tensor([0, 5, 2, -1, 9, 3], dtype=torch.int64)
     rowptr, perm, status = native.csr_build(index.to(DEV), 5)
-    assert int(status.item()) == 1
+    assert status.tolist() == [1, 0]
     # valid edges (0, 2, 3) still form a correct CSR; invalid ones sit behind rowptr[N]
     assert rowptr.cpu().tolist() == [0, 1, 1, 2, 3, 3]
     assert perm.cpu().tolist()[:3] == [0, 2, 5]
 
 
 # ------------------------------------------------------------------ K1 scatter-sum
+def test_permute_index_checked_flags_and_sanitises(native):
+    src = torch.tensor([3, 0, 7, -1, 2, 9], dtype=torch.int64, device=DEV)
+    perm = torch.tensor([5, 4, 3, 2, 1, 0], dtype=torch.int32, device=DEV)
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    out = native.permute_index_checked(src, perm, 8, status)
+    assert out.tolist() == [0, 2, 0, 7, 0, 3] and status.item() == 1  # 9 and -1 flagged, stored as 0
+    status.zero_()
+    out = native.permute_index_checked(src.clamp(0, 7), None, 8, status)
+    assert out.tolist() == [3, 0, 7, 0, 2, 7] and status.item() == 0
+
+
 @pytest.mark.parametrize("d", [1, 3, 4, 8, 12, 16, 32, 64, 100, 128, 256, 260])
 @pytest.mark.parametrize("use_perm", [True, False])
 def test_scatter_sum_bit_exact(native, d, use_perm):
