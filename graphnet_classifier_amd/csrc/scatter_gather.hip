@@ -112,6 +112,15 @@ __global__ __launch_bounds__(gnc::kBlock) void agg_fixup_kernel(const float* __r
   }
 }
 
+// ... and the destinations without any row get their zeros here (one thread per destination; far cheaper than a
+// memset of the whole [N, D] aggregate in front of the edge kernel)
+__global__ __launch_bounds__(gnc::kBlock) void agg_zero_empty_kernel(const int32_t* __restrict__ rowptr, int32_t num_nodes,
+                                                                     int32_t feat_dim, float* __restrict__ out, int64_t ld_out) {
+  const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= num_nodes || rowptr[v] != rowptr[v + 1]) return;
+  for (int c = 0; c < feat_dim; ++c) out[v * ld_out + c] = 0.f;
+}
+
 // K1, generic: any feat_dim / alignment; one wave per destination, scalar columns.
 template <bool HAS_PERM>
 __global__ __launch_bounds__(gnc::kBlock) void scatter_sum_csr_scalar(
@@ -258,13 +267,19 @@ extern "C" int gnc_scatter_sum_csr_f32(const float* src, int64_t ld_src, const i
 extern "C" int gnc_agg_fixup_f32(const float* src, int64_t ld_src, const int32_t* rowptr, const int32_t* fix, int32_t n_fix,
                                  int64_t num_nodes, int32_t feat_dim, float* out, int64_t ld_out, void* stream_) {
   GNC_REQUIRE(n_fix >= 0 && num_nodes >= 0 && num_nodes < INT32_MAX && feat_dim >= 0, "gnc_agg_fixup_f32: bad sizes");
-  if (n_fix == 0 || feat_dim == 0 || num_nodes == 0) return GNC_OK;
-  GNC_REQUIRE(src && rowptr && fix && out, "gnc_agg_fixup_f32: null pointer");
+  if (feat_dim == 0 || num_nodes == 0) return GNC_OK;
+  GNC_REQUIRE(rowptr && out && (n_fix == 0 || (src && fix)), "gnc_agg_fixup_f32: null pointer");
   GNC_REQUIRE(ld_src >= feat_dim && ld_out >= feat_dim, "gnc_agg_fixup_f32: leading dimension < feat_dim");
-  const int64_t blocks = gnc::ceil_div((int64_t)n_fix * 16, gnc::kBlock);
-  agg_fixup_kernel<<<dim3((unsigned)blocks), dim3(gnc::kBlock), 0, (hipStream_t)stream_>>>(src, ld_src, rowptr, fix, n_fix,
-                                                                                          (int32_t)num_nodes, feat_dim, out, ld_out);
-  return gnc::check_launch("agg_fixup_kernel");
+  if (n_fix > 0) {
+    const int64_t blocks = gnc::ceil_div((int64_t)n_fix * 16, gnc::kBlock);
+    agg_fixup_kernel<<<dim3((unsigned)blocks), dim3(gnc::kBlock), 0, (hipStream_t)stream_>>>(src, ld_src, rowptr, fix, n_fix,
+                                                                                            (int32_t)num_nodes, feat_dim, out, ld_out);
+    const int rc = gnc::check_launch("agg_fixup_kernel");
+    if (rc) return rc;
+  }
+  agg_zero_empty_kernel<<<dim3((unsigned)gnc::ceil_div(num_nodes, gnc::kBlock)), dim3(gnc::kBlock), 0, (hipStream_t)stream_>>>(
+      rowptr, (int32_t)num_nodes, feat_dim, out, ld_out);
+  return gnc::check_launch("agg_zero_empty_kernel");
 }
 
 extern "C" int gnc_gather_rows_f32(const float* table, int64_t ld_table, const int32_t* index, int64_t num_rows,

@@ -406,7 +406,7 @@ def mlp_forward(segments, weights, biases, ln=None, activation: str = "ReLU", ac
         dst_of_row, rowptr, num_nodes = aggregate
         _require_cuda(dst_of_row, rowptr)
         if rows > 0 and lib.gnc_mlp_agg_supported(ctypes.byref(desc)) == 0:
-            agg = torch.zeros(num_nodes, out.size(1), dtype=torch.float32, device=dev)  # rows of empty destinations
+            agg = torch.empty(num_nodes, out.size(1), dtype=torch.float32, device=dev)  # fully defined after the fix-up
             fix = torch.empty(lib.gnc_mlp_agg_fix_len(), dtype=torch.int32, device=dev)
             desc.agg_out, desc.ld_agg = agg.data_ptr(), _ld(agg)
             desc.agg_index, desc.agg_fix = dst_of_row.contiguous().data_ptr(), fix.data_ptr()

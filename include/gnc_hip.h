@@ -174,7 +174,7 @@ typedef struct gnc_mlp_desc {
    * added in ascending r starting from 0.0 - bit for bit what gnc_scatter_sum_csr_f32 gives on `out` -
    * for every destination whose rows lie inside ONE wave's contiguous row range.  Contract:
    *   - agg_index [rows] int32 is non-decreasing (rows are in destination-CSR order);
-   *   - the caller zero-fills agg_out first (destinations without rows are never written);
+   *   - destinations without rows are not written by the kernel: gnc_agg_fixup_f32 zero-fills them;
    *   - destinations cut by a range boundary are not written either: the kernel lists them (and -1 for
    *     idle waves) in agg_fix [gnc_mlp_agg_fix_len()] int32, and gnc_agg_fixup_f32 recomputes exactly
    *     those rows from `out` through the row pointers afterwards (same stream).
@@ -196,7 +196,8 @@ int gnc_mlp_forward_f32(const gnc_mlp_desc_t* desc /* host */, void* stream);
 int gnc_mlp_agg_supported(const gnc_mlp_desc_t* desc /* host */);
 int gnc_mlp_agg_fix_len(void); /* entries of agg_fix (2 per wave of the persistent grid) */
 /* out[v, :] = sum over k in [rowptr[v], rowptr[v+1]) of src[k, :] (ascending k) for the n_fix destinations
- * v = fix[j] (entries < 0 or >= num_nodes are skipped; duplicates are harmless). */
+ * v = fix[j] (entries < 0 or >= num_nodes are skipped; duplicates are harmless), and out[v, :] = 0 for every
+ * destination v < num_nodes without rows: together with the epilogue every row of `out` is then defined. */
 int gnc_agg_fixup_f32(const float* src, int64_t ld_src, const int32_t* rowptr, const int32_t* fix, int32_t n_fix,
                       int64_t num_nodes, int32_t feat_dim, float* out, int64_t ld_out, void* stream);
 
