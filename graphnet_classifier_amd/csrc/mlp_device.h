@@ -707,7 +707,8 @@ int validate_desc(const gnc_mlp_desc_t* d, bool check_ptrs);
 int launch_resident(const gnc_mlp_desc_t& d, int T, bool narrow_out, hipStream_t stream, bool* launched,
                     bool probe_only = false);
 // streaming FAST variant (mlp_stream.hip) for widths whose weights do not fit in LDS; same contract
-int launch_stream(const gnc_mlp_desc_t& d, int T, bool narrow_out, hipStream_t stream, bool* launched);
+int launch_stream(const gnc_mlp_desc_t& d, int T, bool narrow_out, hipStream_t stream, bool* launched,
+                  bool probe_only = false);
 // widths 129..256 on v_mfma_f32_16x16x4_f32, 16 rows per wave (mlp_stream16.hip); same contract
 int launch_stream16(const gnc_mlp_desc_t& d, hipStream_t stream, bool* launched);
 

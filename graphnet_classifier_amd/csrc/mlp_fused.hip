@@ -271,9 +271,13 @@ extern "C" int gnc_mlp_agg_supported(const gnc_mlp_desc_t* desc) {
   bool ok = false;
   rc = launch_resident(probe, T, narrow_out, nullptr, &ok, true);
   if (rc) return rc;
+  if (!ok && T == 4) {  // 65..128 features: the streaming kernel carries the epilogue too
+    rc = launch_stream(probe, T, narrow_out, nullptr, &ok, true);
+    if (rc) return rc;
+  }
   if (!ok) {
-    gnc::set_error("gnc_mlp_agg_supported: needs the weights-resident W-split shape (1 MATMUL + 2 ADD segments, "
-                   "residual = the MATMUL segment, widths 33..64)");
+    gnc::set_error("gnc_mlp_agg_supported: needs the weights-resident W-split shape (1 MATMUL + 2 ADD segments, residual = "
+                   "the MATMUL segment, widths 33..64) or a 65..128-wide description of the streaming kernel");
     return GNC_ERR_UNSUPPORTED;
   }
   return GNC_OK;
@@ -293,18 +297,23 @@ extern "C" int gnc_mlp_forward_f32(const gnc_mlp_desc_t* desc, void* stream_) {
   bool launched = false;  // weights-resident variant first (decides by LDS fit)
   rc = launch_resident(*desc, T, narrow_out, stream, &launched);
   if (rc || launched) return rc;
-  if (desc->agg_out) {
+  if (desc->agg_out && T != 4) {
     gnc::set_error("gnc_mlp_forward_f32: the fused aggregation epilogue is not available for this description "
                    "(gnc_mlp_agg_supported)");
     return GNC_ERR_UNSUPPORTED;
   }
   static const bool s16_128 = getenv("GNC_STREAM16_D128") != nullptr;  // A/B: 16-row kernel also for 65..128 features
-  if (T == 8 || (T == 4 && s16_128)) {  // 129..256 features: 16-row tiles on the 16x16x4 MFMA
+  if (T == 8 || (T == 4 && s16_128 && !desc->agg_out)) {  // 129..256 features: 16-row tiles on the 16x16x4 MFMA
     rc = launch_stream16(*desc, stream, &launched);
     if (rc || launched) return rc;
   }
   rc = launch_stream(*desc, T, narrow_out, stream, &launched);  // wide layers: double-buffered weight stream
   if (rc || launched) return rc;
+  if (desc->agg_out) {
+    gnc::set_error("gnc_mlp_forward_f32: the fused aggregation epilogue is not available for this description "
+                   "(gnc_mlp_agg_supported)");
+    return GNC_ERR_UNSUPPORTED;
+  }
 
   switch (T * 2 + (narrow_out ? 1 : 0)) {
     case 1 * 2 + 0: case 1 * 2 + 1: return launch<1, 1>(*desc, stream);

@@ -44,7 +44,11 @@ struct StreamPlan {
 // 256-wide instance, which has no registers to spare).
 // DBUF: two weight buffers and one barrier per chunk; false (256-wide layers, whose 70 KB chunks do not
 // fit twice): one buffer, the prefetched registers are written between two barriers.
-template <int HT, int OT, int WAVES, bool DBUF, bool ADD2>
+// AGG: fused aggregation epilogue (gnc_mlp_desc_t.agg_out, see mlp_resident.hip): every wave owns a CONTIGUOUS range
+// of 32-row tiles and carries the running sum of the destination in progress, one register per 64 output columns;
+// a workgroup still steps through the weight chunks in lockstep, so waves whose range is one tile shorter run a
+// last iteration on a tile past the table's end (loads return zeros / clamped rows, stores are dropped).
+template <int HT, int OT, int WAVES, bool DBUF, bool ADD2, bool AGG = false>
 __global__ __launch_bounds__(WAVES * 64) void mlp_stream_kernel(const gnc_mlp_desc_t d, const StreamPlan pl,
                                                                 const int num_tiles) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -109,22 +113,37 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_stream_kernel(const gnc_mlp_de
     for (int p = 0; p < NW; ++p) *reinterpret_cast<f32x4*>(buf + (p * RPP + wr0) * LDSW + wc4 * 4) = wr[p];
   };
 
+  // Tile schedule in WAVE tiles (32 rows each).  Default: workgroup-tile t = blockIdx.x + k * gridDim.x, the wave takes
+  // rows (t * WAVES + wave) * 32.  AGG: contiguous ranges, see above.  `iters` is workgroup-uniform.
+  const int num_wtiles = (rows + RPW - 1) / RPW;
+  const int gwave = (int)blockIdx.x * WAVES + wave;
+  int agg_t0 = 0, agg_cnt = 0, iters;
+  if constexpr (AGG) {
+    const int tw = (int)gridDim.x * WAVES, q = num_wtiles / tw, rem = num_wtiles - q * tw;
+    agg_t0 = gwave * q + (gwave < rem ? gwave : rem);
+    agg_cnt = q + (gwave < rem ? 1 : 0);
+    iters = q + ((int)blockIdx.x * WAVES < rem ? 1 : 0);
+  } else {
+    iters = (num_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  }
+  auto wtile_of = [&](int k) -> int {  // wave tile of iteration k (>= num_wtiles: past the end)
+    if constexpr (AGG) return k < agg_cnt ? agg_t0 + k : num_wtiles;
+    return ((int)blockIdx.x + k * (int)gridDim.x) * WAVES + wave;
+  };
   // table row of tile row (lane & 31), clamped so the load is always legal
-  const int last_tile = num_tiles - 1;
-  auto load_idx = [&](int tile, int s) -> int {
-    const int tc = tile < last_tile ? tile : last_tile;
-    int r = (tc * WAVES + wave) * RPW + (lane & 31);
+  auto load_idx = [&](int wt, int s) -> int {
+    int r = wt * RPW + (lane & 31);
     r = r < rows ? r : rows - 1;
     const int32_t* ip = d.seg[s].index;
     return ip ? ip[r] : r;
   };
-  // `tile_of` = the tile these rows belong to (row-ordered segments are read through a window at its first row)
+  // `tile_of` = the WAVE tile these rows belong to (row-ordered segments are read through a window at its first row)
   auto load_rows = [&](f32x4 (&pre)[NP], int s, int c0, int idxv, int tile_of) {
     const float* base = d.seg[s].ptr;
     const int ld = d.seg[s].ld;
     const int col = c0 + c4 * 4 < ld ? c0 + c4 * 4 : 0;
     if (d.seg[s].index == nullptr) {
-      load_tile_rows(pre, base, ld, ((int64_t)tile_of * WAVES + wave) * RPW, rows, (uint32_t)(rs * ld + col) * 4u);
+      load_tile_rows(pre, base, ld, (int64_t)tile_of * RPW, rows, (uint32_t)(rs * ld + col) * 4u);
     } else {
       const int64_t tbytes = d.seg[s].table_rows * (int64_t)ld * 4;
       if (tbytes > 0 && tbytes <= 0xffffffffll) {
@@ -164,11 +183,12 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_stream_kernel(const gnc_mlp_de
   // gather ids per segment: ids[s] = ids of the tile whose rows are requested next, ids_next[s] = the
   // tile after that (fetched a whole tile before they are needed)
   int ids[GNC_MAX_SEGMENTS], ids_next[GNC_MAX_SEGMENTS];
-  int tile = blockIdx.x;
+  int kit = 0;               // iteration counter
+  int tile = wtile_of(0);    // wave tile of this iteration
 #pragma unroll
   for (int s = 0; s < GNC_MAX_SEGMENTS; ++s) {
     ids[s] = s < d.num_segments ? load_idx(tile, s) : 0;
-    ids_next[s] = s < d.num_segments ? load_idx(tile + (int)gridDim.x, s) : 0;
+    ids_next[s] = s < d.num_segments ? load_idx(wtile_of(1), s) : 0;
   }
 
   f32x4 cur[NP], cur2[NP];  // rows of the next step to stage (cur2: second segment of a combined ADD)
@@ -209,9 +229,25 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_stream_kernel(const gnc_mlp_de
     }
   };
 
-  while (tile < num_tiles) {
-    const int row0 = (tile * WAVES + wave) * RPW;
-    const int ntile = tile + gridDim.x;
+  // fused aggregation state (AGG): destination ids of the tile's rows, running sums (lane = feature, per 64 columns)
+  constexpr int OCHA = (OT + 1) / 2;
+  auto agg_ids = [&](int wt) -> int {
+    int r = wt * RPW + (lane & 31);
+    r = r < rows ? r : rows - 1;
+    return d.agg_index[r];
+  };
+  int aid = 0, aid_next = 0;
+  float agg_acc[OCHA];
+#pragma unroll
+  for (int c = 0; c < OCHA; ++c) agg_acc[c] = 0.f;
+  int agg_cur = -1, agg_first_dst = -1;  // wave-uniform
+  bool agg_first = true;
+  if constexpr (AGG) aid = agg_ids(tile);
+
+  while (kit < iters) {
+    const int row0 = tile * RPW;
+    const int ntile = wtile_of(kit + 1);
+    if constexpr (AGG) aid_next = agg_ids(ntile);
     int q = 0;
 
     // ------------------------------------------------------------------ first Linear
@@ -236,7 +272,7 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_stream_kernel(const gnc_mlp_de
 #pragma unroll
           for (int k = 0; k < GNC_MAX_SEGMENTS; ++k) {
             ids[k] = ids_next[k];
-            if (k < d.num_segments) ids_next[k] = load_idx(ntile + (int)gridDim.x, k);
+            if (k < d.num_segments) ids_next[k] = load_idx(wtile_of(kit + 2), k);
           }
         }
         int idv = 0;
@@ -314,6 +350,7 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_stream_kernel(const gnc_mlp_de
     for (int p = 0; p < NP; ++p) asm volatile("" ::"v"(cur[p]));
 
     constexpr int OCH = (OT + 1) / 2;
+    float rowv[AGG ? OCH : 1][RPW];  // AGG: final row values per 64-column chunk, lane = feature
 #pragma unroll
     for (int cc = 0; cc < OCH; ++cc) {
       if (cc * KC < out_dim) {
@@ -325,16 +362,79 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_stream_kernel(const gnc_mlp_de
           default: chunk_to_lds<OT, 6>(o, abuf, i, h); break;
         }
         compiler_lds_barrier();
-        store_staged_rows<NP, true>(abuf, d.out + cc * KC, d.ld_out, out_dim - cc * KC < KC ? out_dim - cc * KC : KC, row0, rows, c4, rs,
-                          d.residual ? d.residual + cc * KC : nullptr, d.ld_residual);
+        if constexpr (AGG) {
+          // the residual joins the staged tile first (whole rows), so that the LDS tile holds the FINAL rows
+          // that are both stored and summed per destination
+          const int wcc = out_dim - cc * KC < KC ? out_dim - cc * KC : KC;
+          if (d.residual) {
+            f32x4 rv[NP];
+            load_tile_rows(rv, d.residual + cc * KC, d.ld_residual, row0, rows, (uint32_t)(rs * d.ld_residual + (c4 * 4 < wcc ? c4 * 4 : 0)) * 4u);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+              float* q = abuf + (p * 4 + rs) * LDSW + c4 * 4;
+              *reinterpret_cast<f32x4*>(q) = *reinterpret_cast<const f32x4*>(q) + rv[p];
+            }
+            compiler_lds_barrier();
+          }
+          store_staged_rows<NP, true>(abuf, d.out + cc * KC, d.ld_out, wcc, row0, rows, c4, rs);
+          // this chunk's 32 row values (lane = feature) are kept; ONE scalar walk over the rows follows the last chunk
+#pragma unroll
+          for (int r = 0; r < RPW; ++r) rowv[cc][r] = abuf[r * LDSW + lane];
+        } else {
+          store_staged_rows<NP, true>(abuf, d.out + cc * KC, d.ld_out, out_dim - cc * KC < KC ? out_dim - cc * KC : KC, row0, rows, c4, rs,
+                                      d.residual ? d.residual + cc * KC : nullptr, d.ld_residual);
+        }
+      } else if constexpr (AGG) {
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) rowv[cc][r] = 0.f;
       }
+    }
+    if constexpr (AGG) {
+      // walk of the tile's rows (see mlp_resident.hip): wave-uniform control, one add per row and column chunk
+      const int valid = rows - row0 < RPW ? (rows - row0 > 0 ? rows - row0 : 0) : RPW;
+      int prv = __shfl_up(aid, 1, 64);
+      prv = lane == 0 ? agg_cur : prv;
+      const unsigned long long vmask = valid >= 32 ? 0xffffffffull : ((1ull << valid) - 1ull);
+      const unsigned long long bnd = __ballot(aid != prv) & vmask;
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) {
+        if (r < valid) {
+          if ((bnd >> r) & 1ull) {
+            if (agg_cur >= 0) {
+              if (agg_first) {
+                agg_first = false;
+                agg_first_dst = agg_cur;
+              } else {
+                float* dstp = d.agg_out + (int64_t)agg_cur * d.ld_agg;
+#pragma unroll
+                for (int c = 0; c < OCH; ++c)
+                  if (c * KC + lane < out_dim)
+                    asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2\n\ts_nop 0" ::"v"((c * KC + lane) * 4), "v"(agg_acc[c]), "s"(dstp) : "memory");
+              }
+            }
+            agg_cur = __builtin_amdgcn_readlane(aid, r);
+#pragma unroll
+            for (int c = 0; c < OCH; ++c) agg_acc[c] = 0.f;
+          }
+#pragma unroll
+          for (int c = 0; c < OCH; ++c) agg_acc[c] += rowv[c][r];
+        }
+      }
+      aid = aid_next;
     }
     compiler_lds_barrier();
     tile = ntile;
+    ++kit;
+  }
+  if constexpr (AGG) {
+    if (lane == 0) {
+      d.agg_fix[2 * gwave] = agg_first ? agg_cur : agg_first_dst;
+      d.agg_fix[2 * gwave + 1] = agg_cur;
+    }
   }
 }
 
-template <int HT, int OT, int WAVES, bool DBUF, bool ADD2>
+template <int HT, int OT, int WAVES, bool DBUF, bool ADD2, bool AGG = false>
 int launch(const gnc_mlp_desc_t& d, const StreamPlan& pl, hipStream_t stream) {
   constexpr int WT = HT > OT ? HT : OT;
   const size_t smem =
@@ -345,7 +445,7 @@ int launch(const gnc_mlp_desc_t& d, const StreamPlan& pl, hipStream_t stream) {
   }
   static bool attr_set = false;
   if (!attr_set) {
-    int rc = gnc::check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_stream_kernel<HT, OT, WAVES, DBUF, ADD2>),
+    int rc = gnc::check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_stream_kernel<HT, OT, WAVES, DBUF, ADD2, AGG>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
                             "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc) return rc;
@@ -353,7 +453,8 @@ int launch(const gnc_mlp_desc_t& d, const StreamPlan& pl, hipStream_t stream) {
   }
   const int64_t num_tiles = gnc::ceil_div(d.rows, (int64_t)WAVES * RPW);
   int64_t grid = num_tiles < gnc::kNumCU ? num_tiles : gnc::kNumCU;  // one persistent workgroup per CU
-  mlp_stream_kernel<HT, OT, WAVES, DBUF, ADD2><<<dim3((unsigned)grid), dim3(WAVES * 64), smem, stream>>>(d, pl, (int)num_tiles);
+  if constexpr (AGG) grid = gnc::kNumCU;  // agg_fix has two entries for every wave of the full grid (8 waves per workgroup)
+  mlp_stream_kernel<HT, OT, WAVES, DBUF, ADD2, AGG><<<dim3((unsigned)grid), dim3(WAVES * 64), smem, stream>>>(d, pl, (int)num_tiles);
   return gnc::check_launch("mlp_stream_kernel");
 }
 
@@ -361,10 +462,11 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace
 
-int gnc_mlp::launch_stream(const gnc_mlp_desc_t& d, int T, bool narrow_out, hipStream_t stream, bool* launched) {
+int gnc_mlp::launch_stream(const gnc_mlp_desc_t& d, int T, bool narrow_out, hipStream_t stream, bool* launched,
+                           bool probe_only) {
   *launched = false;
   static const bool disabled = getenv("GNC_MLP_NO_STREAM2") != nullptr;  // A/B switch for benchmarking
-  if (disabled || d.rows >= INT32_MAX) return GNC_OK;
+  if (disabled || d.rows >= INT32_MAX - (1 << 22)) return GNC_OK;  // row numbers of prefetched tiles stay below 2^31
   const int L = d.num_linear;
   if (L > 1 && d.activation != GNC_ACT_RELU) return GNC_OK;
   if (d.residual && (d.ld_residual % 4 != 0 || !al16(d.residual))) return GNC_OK;
@@ -401,7 +503,16 @@ int gnc_mlp::launch_stream(const gnc_mlp_desc_t& d, int T, bool narrow_out, hipS
       pl.wc[pl.num_wchunks++] = {(short)l, (short)(c * KC), (short)d.in_dim[l], 0};
     }
 
+  if (d.agg_out) {  // fused aggregation epilogue: the 128-wide instance, whole 16-B output pieces
+    const int od = d.out_dim[L - 1];
+    if (!(T == 4 && !narrow_out && od % 4 == 0 && d.ld_out % 4 == 0 && al16(d.out) && d.agg_index && d.agg_fix && d.ld_agg >= od))
+      return GNC_OK;
+    *launched = true;
+    if (probe_only) return GNC_OK;
+    return launch<4, 4, 8, true, false, true>(d, pl, stream);
+  }
   *launched = true;
+  if (probe_only) return GNC_OK;
   if (narrow_out) {  // out width <= 32 (the decoder): one output tile
     switch (T) {
       case 1: return launch<1, 1, 8, true, true>(d, pl, stream);

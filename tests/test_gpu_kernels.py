@@ -277,13 +277,14 @@ def test_mlp_additive_segments_equal_concat_form(native, d):
     assert max_abs(y.cpu(), ref) < 1e-5
 
 
+@pytest.mark.parametrize("d", [64, 128])
 @pytest.mark.parametrize("n,e,hot", [(211, 1500, 0), (40, 33, 0), (5000, 70001, 0), (3000, 90000, 30000), (7, 4096, 0)])
-def test_fused_aggregation_epilogue_bit_equals_k1(native, n, e, hot):
+def test_fused_aggregation_epilogue_bit_equals_k1(native, n, e, hot, d):
     """the edge kernel's segmented-sum epilogue (gnc_mlp_desc_t.agg_out) + gnc_agg_fixup_f32 give,
     bit for bit, what K1 gives on the stored rows: empty destinations, tails, more waves than tiles, one
-    destination spanning many waves' ranges (`hot` rows of destination 5)."""
-    d = 64
-    rng = np.random.default_rng(n + e)
+    destination spanning many waves' ranges (`hot` rows of destination 5).  d = 64: weights-resident kernel,
+    d = 128: streaming kernel (two 64-column chunks per tile)."""
+    rng = np.random.default_rng(n + e + d)
     sd = _mlp_sd(rng, 3 * d, d, d, 2, True)
     dst = rng.integers(0, n, size=e)
     if hot:
@@ -306,7 +307,7 @@ def test_fused_aggregation_epilogue_bit_equals_k1(native, n, e, hot):
     y0 = native.mlp_forward(segs, ws, bs, ln=ln, residual=ea, modes=modes)
     y, agg = native.mlp_forward(segs, ws, bs, ln=ln, residual=ea, modes=modes,
                                 aggregate=(torch.from_numpy(dst).to(DEV), rowptr, n))
-    assert agg is not None, "the W-split edge shape at width 64 must take the fused epilogue"
+    assert agg is not None, "the W-split edge shape at widths 64 and 128 must take the fused epilogue"
     assert torch.equal(y, y0)
     ref = native.scatter_sum_csr(y, rowptr, None, n)
     assert torch.equal(agg, ref)
@@ -316,12 +317,12 @@ def test_fused_aggregation_epilogue_bit_equals_k1(native, n, e, hot):
 
 def test_fused_aggregation_falls_back_when_the_shape_cannot_carry_it(native):
     rng = np.random.default_rng(5)
-    x = torch.from_numpy(rng.standard_normal((100, 128)).astype(np.float32)).to(DEV)
-    w = torch.from_numpy(rng.standard_normal((128, 128)).astype(np.float32)).to(DEV)
+    x = torch.from_numpy(rng.standard_normal((100, 256)).astype(np.float32)).to(DEV)  # 256 wide: the 16-row kernel
+    w = torch.from_numpy(rng.standard_normal((256, 256)).astype(np.float32)).to(DEV)
     dst = torch.arange(100, dtype=torch.int32, device=DEV)
     rowptr = torch.arange(101, dtype=torch.int32, device=DEV)
     y, agg = native.mlp_forward([(x, None)], [w], [None], aggregate=(dst, rowptr, 100))
-    assert agg is None and max_abs(y.cpu(), x.cpu() @ w.cpu().t()) < 1e-4
+    assert agg is None and max_abs(y.cpu(), x.cpu() @ w.cpu().t()) < 2e-4
 
 
 def test_gather_window_id_outside_the_stated_table_reads_zero(native):
