@@ -315,6 +315,40 @@ def test_fused_aggregation_epilogue_bit_equals_k1(native, n, e, hot, d):
     assert torch.equal(agg.cpu(), O.scatter_sum(y.cpu(), torch.from_numpy(dst).long(), dim_size=n))
 
 
+@pytest.mark.parametrize("d", [64, 128])
+def test_fused_aggregation_random_shapes(native, d):
+    """Twelve random (nodes, edges, degree law) draws per width, including power-law degrees, all edges on one
+    destination and row counts around multiples of the tile and of the grid's wave count."""
+    rng = np.random.default_rng(4242 + d)
+    sd = _mlp_sd(rng, 3 * d, d, d, 2, True)
+    w0 = sd["m.model.0.weight"].to(DEV)
+    ws = [w0[:, 2 * d:], sd["m.model.2.weight"].to(DEV), sd["m.model.4.weight"].to(DEV)]
+    bs = [sd[f"m.model.{i}.bias"].to(DEV) for i in (0, 2, 4)]
+    ln = (sd["m.model.5.weight"].to(DEV), sd["m.model.5.bias"].to(DEV), 1e-5)
+    modes = [native.SEG_ADD, native.SEG_ADD, native.SEG_MATMUL]
+    sizes = [(1, 1), (3, 31), (3, 32), (9, 33), (100, 2047), (100, 2048 * 32), (100, 2048 * 32 + 1), (4000, 65537),
+             (50000, 50000), (17, 70000), (1000, 123457), (2, 99999)]
+    for k, (n, e) in enumerate(sizes):
+        if k % 3 == 0:
+            dst = rng.integers(0, n, size=e)
+        elif k % 3 == 1:
+            dst = np.minimum((rng.pareto(1.2, size=e)).astype(np.int64), n - 1)   # heavy tail on low ids
+        else:
+            dst = np.full(e, n - 1)                                                # one destination takes everything
+        dst = np.sort(dst).astype(np.int32)
+        src = rng.integers(0, n, size=e).astype(np.int32)
+        x = torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32)).to(DEV)
+        ea = torch.from_numpy(rng.standard_normal((e, d)).astype(np.float32)).to(DEV)
+        rowptr = torch.from_numpy(np.concatenate([[0], np.cumsum(np.bincount(dst, minlength=n))]).astype(np.int32)).to(DEV)
+        ps = native.mlp_forward([(x, None)], [w0[:, :d]], [None])
+        pd = native.mlp_forward([(x, None)], [w0[:, d:2 * d]], [None])
+        dst_t = torch.from_numpy(dst).to(DEV)
+        y, agg = native.mlp_forward([(ps, torch.from_numpy(src).to(DEV)), (pd, dst_t), (ea, None)], ws, bs, ln=ln, residual=ea,
+                                    modes=modes, aggregate=(dst_t, rowptr, n))
+        assert agg is not None
+        assert torch.equal(agg, native.scatter_sum_csr(y, rowptr, None, n)), (n, e, k)
+
+
 def test_fused_aggregation_falls_back_when_the_shape_cannot_carry_it(native):
     rng = np.random.default_rng(5)
     x = torch.from_numpy(rng.standard_normal((100, 256)).astype(np.float32)).to(DEV)  # 256 wide: the 16-row kernel
