@@ -10,8 +10,11 @@
 //   MATMUL steps first  - rows land in registers, go to the wave's LDS tile, feed MFMAs;
 //                         the loads of the NEXT step are issued before the MFMAs start;
 //   one combined ADD step - the W-split's pre-projected rows (ps[src], pd[dst]) are summed in
-//                         registers, staged once and added to the pre-activation; their loads
-//                         fly under the last MATMUL step's MFMAs;
+//                         registers, staged once and added to the pre-activation; their loads are
+//                         issued from INSIDE the last MATMUL step's MFMA loop, one 4-row piece per
+//                         k-group (a wave's LDS / VMEM / scalar instructions ride in the shadow of its
+//                         own MFMAs; in front of the loop they would crawl whenever the SIMD mate is
+//                         in an MFMA phase);
 //   the first step's rows of the NEXT tile are requested right after that and have the
 //   remaining Linear layers, LayerNorm and epilogue (>= 8k cycles) to land.  Gather ids are
 //   fetched one tile earlier still, with one coalesced load per segment and tile.
@@ -26,8 +29,11 @@
 //     (rows past the end read as 0, rows past the end are never stored - the hardware bounds check
 //     does both), gather ids are clamped; there is no exec-masked VMEM in the loop.
 // fp32 MFMA time and VALU time ADD UP on a gfx950 SIMD (tools/hw_probe.hip), so the loop keeps the
-// vector unit out of address arithmetic: windows are built by the scalar unit, per-lane offsets are
-// loop constants, gathered rows cost one v_lshl_add_u64 each.
+// vector unit out of address arithmetic: full tiles use one loop-invariant descriptor over the whole
+// table with the piece offsets in the instruction's SGPR offset field, per-lane offsets are loop
+// constants, gathered rows cost one v_add_u32 each.
+// Optional epilogue (template flag AGG, gnc_mlp_desc_t.agg_out): per-destination sums of the output rows,
+// bit-identical to K1 (see the comment at the kernel).
 // Requirements checked by the launcher (anything else runs the streaming kernel): ReLU,
 // all tables / weights / output 16-B aligned with leading dimensions % 4 == 0, every segment
 // <= 64 columns, MATMUL segments listed before ADD segments, rows < 2^31, gathered tables with a stated
