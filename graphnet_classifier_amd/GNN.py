@@ -73,9 +73,9 @@ class EdgeProcessor(nn.Module):
 
     def forward_sorted(self, x: Tensor, topo: GraphTopology, edge_attr: Tensor, aggregate: bool = False):
         """Same math with the two row gathers fused into the kernel; ``edge_attr`` and the
-        result are in destination-sorted edge order.  ``aggregate=True`` (inference only) returns
-        ``(e', agg)`` where ``agg`` is the per-destination sum of ``e'`` formed in the same launch, or None
-        when that launch cannot carry it."""
+        result are in destination-sorted edge order.  ``aggregate=True`` returns ``(e', agg)`` where ``agg`` is the
+        per-destination sum of ``e'`` formed in the same launch, or None when this path cannot provide it (the
+        caller then runs K1)."""
         mlp = self.edge_processor
         norm = mlp.model[-1] if mlp.norm_type is not None else None
         lin = mlp._linears()
@@ -83,9 +83,12 @@ class EdgeProcessor(nn.Module):
                 and lin[0].in_features == 2 * x.size(1) + edge_attr.size(1) and x.size(1) % 4 == 0):
             # W-split of the first Linear: node-side products once per node, gathered and added per edge
             ln = (norm.weight, norm.bias, norm.eps) if isinstance(norm, nn.LayerNorm) else None
-            if aggregate:
+            if aggregate and not torch.is_grad_enabled():
                 return Fn.edge_processor_wsplit_aggregated(x, edge_attr, topo, [m.weight for m in lin], [m.bias for m in lin],
                                                            ln, mlp.activation_name, mlp._act_param())
+            if aggregate:  # training: same launch, both outputs differentiable
+                return Fn.edge_processor_wsplit(x, edge_attr, topo, [m.weight for m in lin], [m.bias for m in lin], ln,
+                                                mlp.activation_name, mlp._act_param(), with_agg=True)
             return Fn.edge_processor_wsplit(x, edge_attr, topo, [m.weight for m in lin],
                                             [m.bias for m in lin], ln, mlp.activation_name, mlp._act_param())
         out = mlp.forward_segments(
@@ -149,9 +152,9 @@ class MetaLayer(nn.Module):
     def forward_sorted(self, x: Tensor, topo: GraphTopology, edge_attr: Tensor):
         agg = None
         if self.edge_model is not None:
-            # inference: let the edge launch form the node model's aggregate in its epilogue;
-            # with autograd on, K1 stays a separate differentiable launch
-            if (FUSED_AGG and self.node_model is not None and not torch.is_grad_enabled()
+            # let the edge launch form the node model's aggregate in its epilogue; with autograd on the
+            # W-split Function returns both outputs and folds the aggregate's gradient (a gather) into e''s
+            if (FUSED_AGG and self.node_model is not None
                     and isinstance(self.edge_model, EdgeProcessor) and isinstance(self.node_model, NodeProcessor)):
                 edge_attr, agg = self.edge_model.forward_sorted(x, topo, edge_attr, aggregate=True)
             else:

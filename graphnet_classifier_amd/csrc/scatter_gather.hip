@@ -146,11 +146,12 @@ __global__ __launch_bounds__(gnc::kBlock) void scatter_sum_csr_scalar(
 // ---------------------------------------------------------------------------------------
 // K2 row gather: out[r, :] = table[index[r], :]
 // ---------------------------------------------------------------------------------------
-template <int LPR>
+template <int LPR, bool ADD = false>
 __global__ __launch_bounds__(gnc::kBlock) void gather_rows_vec4(const float* __restrict__ table, int64_t ld_table,
                                                                 const int32_t* __restrict__ index,
                                                                 int64_t num_rows, int32_t feat_dim,
-                                                                float* __restrict__ out, int64_t ld_out) {
+                                                                float* __restrict__ out, int64_t ld_out,
+                                                                const float* __restrict__ addend = nullptr, int64_t ld_add = 0) {
   constexpr int RPB = gnc::kBlock / LPR;  // rows per block pass
   const int sub = threadIdx.x % LPR;
   const int col = sub * 4;
@@ -160,25 +161,37 @@ __global__ __launch_bounds__(gnc::kBlock) void gather_rows_vec4(const float* __r
   // two rows in flight per lane
   for (; r + stride < num_rows; r += 2 * stride) {
     const int32_t i0 = index[r], i1 = index[r + stride];
-    const f4 a = ld4(table + (int64_t)i0 * ld_table + col);
-    const f4 b = ld4(table + (int64_t)i1 * ld_table + col);
+    f4 a = ld4(table + (int64_t)i0 * ld_table + col);
+    f4 b = ld4(table + (int64_t)i1 * ld_table + col);
+    if (ADD) {
+      acc4(a, ld4_stream(addend + r * ld_add + col));
+      acc4(b, ld4_stream(addend + (r + stride) * ld_add + col));
+    }
     st4(out + r * ld_out + col, a);
     st4(out + (r + stride) * ld_out + col, b);
   }
-  if (r < num_rows) st4(out + r * ld_out + col, ld4(table + (int64_t)index[r] * ld_table + col));
+  if (r < num_rows) {
+    f4 a = ld4(table + (int64_t)index[r] * ld_table + col);
+    if (ADD) acc4(a, ld4_stream(addend + r * ld_add + col));
+    st4(out + r * ld_out + col, a);
+  }
 }
 
+template <bool ADD = false>
 __global__ __launch_bounds__(gnc::kBlock) void gather_rows_scalar(const float* __restrict__ table, int64_t ld_table,
                                                                   const int32_t* __restrict__ index,
                                                                   int64_t num_rows, int32_t feat_dim,
-                                                                  float* __restrict__ out, int64_t ld_out) {
+                                                                  float* __restrict__ out, int64_t ld_out,
+                                                                  const float* __restrict__ addend = nullptr, int64_t ld_add = 0) {
   const int64_t total = num_rows * feat_dim;
   int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; t < total; t += stride) {
     const int64_t r = t / feat_dim;
     const int c = (int)(t - r * feat_dim);
-    out[r * ld_out + c] = table[(int64_t)index[r] * ld_table + c];
+    float v = table[(int64_t)index[r] * ld_table + c];
+    if (ADD) v += addend[r * ld_add + c];
+    out[r * ld_out + c] = v;
   }
 }
 
@@ -282,24 +295,21 @@ extern "C" int gnc_agg_fixup_f32(const float* src, int64_t ld_src, const int32_t
   return gnc::check_launch("agg_zero_empty_kernel");
 }
 
-extern "C" int gnc_gather_rows_f32(const float* table, int64_t ld_table, const int32_t* index, int64_t num_rows,
-                                   int32_t feat_dim, float* out, int64_t ld_out, void* stream_) {
-  GNC_REQUIRE(num_rows >= 0 && feat_dim >= 0, "gnc_gather_rows_f32: negative size");
-  if (num_rows == 0 || feat_dim == 0) return GNC_OK;
-  GNC_REQUIRE(table && index && out, "gnc_gather_rows_f32: null pointer");
-  GNC_REQUIRE(ld_table >= feat_dim && ld_out >= feat_dim, "gnc_gather_rows_f32: leading dimension < feat_dim");
-  hipStream_t stream = (hipStream_t)stream_;
+namespace {
+template <bool ADD>
+int launch_gather(const float* table, int64_t ld_table, const int32_t* index, const float* addend, int64_t ld_add,
+                  int64_t num_rows, int32_t feat_dim, float* out, int64_t ld_out, hipStream_t stream) {
   const int64_t cap = gnc::kNumCU * 16;
-  if (vec4_ok(table, ld_table, feat_dim) && vec4_ok(out, ld_out, feat_dim)) {
+  if (vec4_ok(table, ld_table, feat_dim) && vec4_ok(out, ld_out, feat_dim) && (!ADD || vec4_ok(addend, ld_add, feat_dim))) {
     const int lpr = pow2_lanes_for(feat_dim);
     int64_t blocks = gnc::ceil_div(num_rows, 2 * (gnc::kBlock / lpr));
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     dim3 grid((unsigned)blocks), block(gnc::kBlock);
     switch (lpr) {
-#define GNC_CASE(L)                                                                                            \
-  case L:                                                                                                      \
-    gather_rows_vec4<L><<<grid, block, 0, stream>>>(table, ld_table, index, num_rows, feat_dim, out, ld_out); \
+#define GNC_CASE(L)                                                                                                            \
+  case L:                                                                                                                      \
+    gather_rows_vec4<L, ADD><<<grid, block, 0, stream>>>(table, ld_table, index, num_rows, feat_dim, out, ld_out, addend, ld_add); \
     break;
       GNC_CASE(1) GNC_CASE(2) GNC_CASE(4) GNC_CASE(8) GNC_CASE(16) GNC_CASE(32) GNC_CASE(64)
 #undef GNC_CASE
@@ -311,9 +321,30 @@ extern "C" int gnc_gather_rows_f32(const float* table, int64_t ld_table, const i
   }
   int64_t blocks = gnc::ceil_div(num_rows * feat_dim, gnc::kBlock);
   if (blocks > cap) blocks = cap;
-  gather_rows_scalar<<<dim3((unsigned)blocks), dim3(gnc::kBlock), 0, stream>>>(table, ld_table, index, num_rows,
-                                                                                feat_dim, out, ld_out);
+  gather_rows_scalar<ADD><<<dim3((unsigned)blocks), dim3(gnc::kBlock), 0, stream>>>(table, ld_table, index, num_rows, feat_dim,
+                                                                                     out, ld_out, addend, ld_add);
   return gnc::check_launch("gather_rows_scalar");
+}
+}  // namespace
+
+extern "C" int gnc_gather_rows_f32(const float* table, int64_t ld_table, const int32_t* index, int64_t num_rows,
+                                   int32_t feat_dim, float* out, int64_t ld_out, void* stream_) {
+  GNC_REQUIRE(num_rows >= 0 && feat_dim >= 0, "gnc_gather_rows_f32: negative size");
+  if (num_rows == 0 || feat_dim == 0) return GNC_OK;
+  GNC_REQUIRE(table && index && out, "gnc_gather_rows_f32: null pointer");
+  GNC_REQUIRE(ld_table >= feat_dim && ld_out >= feat_dim, "gnc_gather_rows_f32: leading dimension < feat_dim");
+  return launch_gather<false>(table, ld_table, index, nullptr, 0, num_rows, feat_dim, out, ld_out, (hipStream_t)stream_);
+}
+
+extern "C" int gnc_gather_rows_add_f32(const float* table, int64_t ld_table, const int32_t* index, const float* addend,
+                                       int64_t ld_addend, int64_t num_rows, int32_t feat_dim, float* out, int64_t ld_out,
+                                       void* stream_) {
+  GNC_REQUIRE(num_rows >= 0 && feat_dim >= 0, "gnc_gather_rows_add_f32: negative size");
+  if (num_rows == 0 || feat_dim == 0) return GNC_OK;
+  GNC_REQUIRE(table && index && addend && out, "gnc_gather_rows_add_f32: null pointer");
+  GNC_REQUIRE(ld_table >= feat_dim && ld_out >= feat_dim && ld_addend >= feat_dim,
+              "gnc_gather_rows_add_f32: leading dimension < feat_dim");
+  return launch_gather<true>(table, ld_table, index, addend, ld_addend, num_rows, feat_dim, out, ld_out, (hipStream_t)stream_);
 }
 
 extern "C" int gnc_edge_features_f32(const float* pos, int32_t space_dim, const int32_t* src, const int32_t* dst,

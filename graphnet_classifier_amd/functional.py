@@ -202,7 +202,8 @@ class _EdgeProcessorWSplit(torch.autograd.Function):
     @staticmethod
     def forward(ctx, meta, topo, x, e, *params):
         ctx.topo = topo
-        src, dst, num_linear, activation, act_param, ln_eps, has_ln = meta
+        src, dst, num_linear, activation, act_param, ln_eps, has_ln = meta[:7]
+        with_agg = len(meta) > 7 and meta[7]
         weights, biases = list(params[:num_linear]), list(params[num_linear:2 * num_linear])
         ln = (params[2 * num_linear], params[2 * num_linear + 1], ln_eps) if has_ln else None
         dn = x.size(1)
@@ -211,15 +212,32 @@ class _EdgeProcessorWSplit(torch.autograd.Function):
         pd = native.mlp_forward([(x, None)], [w0[:, dn:2 * dn]], [None])     # [N, H] = x Wd^T
         out = native.mlp_forward([(ps, src), (pd, dst), (e, None)], [w0[:, 2 * dn:]] + weights[1:], biases, ln=ln,
                                  activation=activation, act_param=act_param, residual=e, rows=e.size(0),
-                                 modes=[native.SEG_ADD, native.SEG_ADD, native.SEG_MATMUL])
-        ctx.meta = meta
+                                 modes=[native.SEG_ADD, native.SEG_ADD, native.SEG_MATMUL],
+                                 aggregate=(topo.dst_sorted, topo.rowptr, topo.num_nodes) if with_agg else None)
+        ctx.meta = meta[:7]
+        ctx.with_agg = with_agg
+        ctx.set_materialize_grads(False)  # an unused output (the last block's e') arrives as None, not as zeros
         ctx.save_for_backward(x, e, *params)
-        return out
+        if not with_agg:
+            return out
+        out, agg = out
+        if agg is None:  # the launch shape cannot carry the epilogue: K1 as a separate launch
+            agg = native.scatter_sum_csr(out, topo.rowptr, None, topo.num_nodes)
+        return out, agg
 
     @staticmethod
-    def backward(ctx, grad_out):
+    def backward(ctx, grad_out, grad_agg=None):
         src, dst, num_linear, activation, act_param, ln_eps, has_ln = ctx.meta
+        if ctx.with_agg:
+            # e' feeds the aggregation (its backward is a row gather by destination) AND whatever consumed e' itself:
+            # both gradients in one pass
+            if grad_agg is not None and grad_out is not None:
+                grad_out = native.gather_rows_add(grad_agg.contiguous(), dst, grad_out.contiguous())
+            elif grad_agg is not None:
+                grad_out = native.gather_rows(grad_agg.contiguous(), dst)
         need = ctx.needs_input_grad[2:]
+        if grad_out is None:
+            return (None, None) + tuple(None for _ in need)
         hip = _edge_wsplit_backward_hip(ctx, grad_out) if HIP_BACKWARD else None
         if hip is not None:
             return (None, None) + hip
@@ -296,9 +314,11 @@ def _edge_wsplit_backward_hip(ctx, grad_out):
     return tuple(g if n else None for g, n in zip(grads, need))
 
 
-def edge_processor_wsplit(x, e, topo, weights, biases, ln, activation="ReLU", act_param=0.0):
+def edge_processor_wsplit(x, e, topo, weights, biases, ln, activation="ReLU", act_param=0.0, with_agg=False):
+    """``with_agg=True`` returns ``(e', agg)``: the per-destination sums come from the edge launch's epilogue (or
+    from K1 when that launch cannot carry it) and both outputs are differentiable."""
     meta = (topo.src_sorted, topo.dst_sorted, len(weights), activation, float(act_param),
-            float(ln[2]) if ln is not None else 0.0, ln is not None)
+            float(ln[2]) if ln is not None else 0.0, ln is not None, bool(with_agg))
     args = list(weights) + list(biases) + ([ln[0], ln[1]] if ln is not None else [])
     return _EdgeProcessorWSplit.apply(meta, topo, x, e, *args)
 

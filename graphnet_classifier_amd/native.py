@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 GNC_MAX_SEGMENTS = 4
 GNC_MAX_LINEAR = 8
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 ACTIVATIONS = {  # nn.<Name> accepted by the reference's MLP(activation=...) (models/MLP.py:21)
     "ReLU": 0, "Identity": 1, "Tanh": 2, "Sigmoid": 3, "SiLU": 4, "GELU": 5, "LeakyReLU": 6, "ELU": 7,
@@ -40,6 +40,8 @@ _SIGNATURES = {
     "gnc_scatter_sum_csr_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p,
                                           c_int64, c_void_p]),
     "gnc_gather_rows_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p]),
+    "gnc_gather_rows_add_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_int64,
+                                          c_void_p]),
     "gnc_edge_features_f32": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     "gnc_sizeof_mlp_desc": (c_size_t, []),
     "gnc_mlp_supported": (c_int32, [c_void_p]),
@@ -277,6 +279,23 @@ def gather_rows(table: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
     with torch.cuda.device(table.device):
         _check(lib.gnc_gather_rows_f32(table.data_ptr(), _ld(table), index.data_ptr(), n, d, out.data_ptr(), _ld(out),
                                        _stream(table)), "gnc_gather_rows_f32")
+    return out
+
+
+def gather_rows_add(table: torch.Tensor, index: torch.Tensor, addend: torch.Tensor) -> torch.Tensor:
+    """out[r] = table[index[r]] + addend[r] in one pass."""
+    lib = load_library()
+    _require_cuda(table, index, addend)
+    table, addend = _rowmajor(table), _rowmajor(addend)
+    if index.dtype != torch.int32:
+        raise TypeError("gather_rows_add expects an int32 index")
+    n, d = index.numel(), table.size(1)
+    if addend.shape != (n, d):
+        raise ValueError(f"addend must be [{n}, {d}], got {tuple(addend.shape)}")
+    out = torch.empty(n, d, dtype=torch.float32, device=table.device)
+    with torch.cuda.device(table.device):
+        _check(lib.gnc_gather_rows_add_f32(table.data_ptr(), _ld(table), index.data_ptr(), addend.data_ptr(), _ld(addend), n, d,
+                                           out.data_ptr(), _ld(out), _stream(table)), "gnc_gather_rows_add_f32")
     return out
 
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GNC_ABI_VERSION 9
+#define GNC_ABI_VERSION 10
 
 enum {
   GNC_OK = 0,
@@ -97,6 +97,10 @@ int gnc_scatter_sum_csr_f32(const float* src, int64_t ld_src, const int32_t* row
  */
 int gnc_gather_rows_f32(const float* table, int64_t ld_table, const int32_t* index, int64_t num_rows,
                         int32_t feat_dim, float* out, int64_t ld_out, void* stream);
+/* out[r, :] = table[index[r], :] + addend[r, :]: the gradient of an edge latent that feeds both the aggregation
+ * (backward of K1 = this gather) and the next block (addend), formed in one pass. */
+int gnc_gather_rows_add_f32(const float* table, int64_t ld_table, const int32_t* index, const float* addend,
+                            int64_t ld_addend, int64_t num_rows, int32_t feat_dim, float* out, int64_t ld_out, void* stream);
 
 /* ---- K6: edge features ------------------------------------------------------------------
  * Replaces models/GNN.py:299-302:  rel = pos[dst[e]] - pos[src[e]];  out[e] = [rel, sum|rel|].

@@ -127,6 +127,17 @@ def test_gather_rows(native, d):
     assert torch.equal(out.cpu(), table[idx.long()])
 
 
+@pytest.mark.parametrize("d", [3, 16, 64, 100, 128])
+def test_gather_rows_add(native, d):
+    """out[r] = table[index[r]] + addend[r] (gradient of an edge latent that feeds the aggregation and the next block)."""
+    rng = np.random.default_rng(d)
+    table = torch.from_numpy(rng.standard_normal((77, d)).astype(np.float32))
+    add = torch.from_numpy(rng.standard_normal((1001, d)).astype(np.float32))
+    idx = torch.from_numpy(rng.integers(0, 77, size=1001).astype(np.int32))
+    out = native.gather_rows_add(table.to(DEV), idx.to(DEV), add.to(DEV))
+    assert torch.equal(out.cpu(), table[idx.long()] + add)
+
+
 @pytest.mark.parametrize("space_dim", [1, 2, 3])
 def test_edge_features(native, space_dim):
     rng = np.random.default_rng(space_dim)
