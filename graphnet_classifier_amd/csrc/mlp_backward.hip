@@ -96,6 +96,7 @@ struct BwdArgs {
   int ld_dx;
   float* yhat;                 // [rows, out_dim] normalised pre-affine output (only with LayerNorm)
   int dx_add_grad_out;         // add grad_out rows to dx (the residual path of a segment that is also the residual)
+  float* ln_partial;           // nullable: [waves, 2 * out_dim] per-wave [colsum(grad_out) | colsum(grad_out * yhat)]
 };
 
 // HT = tiles of the hidden AND output width (both <= 64).  NMM / NADD as in mlp_resident.hip.
@@ -194,6 +195,9 @@ __global__ __launch_bounds__(BNT) void mlp_backward_data_kernel(const gnc_mlp_de
     compiler_lds_barrier();
   };
 
+  // LayerNorm parameter gradients formed in flight (b.ln_partial): lane (rs, c4) sums columns c4*4..+3 of the rows
+  // p*4+rs of all its tiles - 8 registers instead of a [rows, out_dim] y_hat tensor written here and read back
+  f32x4 sum_g = {0.f, 0.f, 0.f, 0.f}, sum_gy = {0.f, 0.f, 0.f, 0.f};
   for (int wt = (int)blockIdx.x * BWAVES + wave; wt < num_wtiles; wt += total_waves) {
     const int row0 = wt * RPW;
 
@@ -254,7 +258,25 @@ __global__ __launch_bounds__(BNT) void mlp_backward_data_kernel(const gnc_mlp_de
       init_bias<HT>(y, pbuf + (L - 1) * PSTRIDE, h);
       mma_chunk_from_regs<HT, HT>(y, hid, wres + (NMM + L - 2) * CH, 0, d.in_dim[L - 1], i, h);
       layer_norm_backward_tiles<HT>(y, g, pbuf + L * PSTRIDE, out_dim, d.ln_eps, h);
-      emit(y, b.yhat, out_dim, out_dim, row0);  // normalised pre-affine output: d gamma = colsum(grad_out * yhat)
+      if (b.ln_partial) {
+        // y_hat goes through the wave's LDS tile into whole-row pieces; grad_out's pieces come back through the
+        // window (this tile read them a moment ago: L2 hits; rows past the end read 0 and drop out)
+        compiler_lds_barrier();
+        tiles_to_lds<HT>(y, abuf, i, h);
+        compiler_lds_barrier();
+        f32x4 gp[NP];
+        const int gcol = c4 * 4 < out_dim ? c4 * 4 : 0;
+        load_tile_rows(gp, b.grad_out, b.ld_grad_out, row0, rows, (uint32_t)(rs * b.ld_grad_out + gcol) * 4u);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const f32x4 yh = *reinterpret_cast<const f32x4*>(abuf + (p * 4 + rs) * LDSW + c4 * 4);
+          sum_g += gp[p];
+          sum_gy = __builtin_elementwise_fma(gp[p], yh, sum_gy);
+        }
+        compiler_lds_barrier();
+      } else {
+        emit(y, b.yhat, out_dim, out_dim, row0);  // normalised pre-affine output: d gamma = colsum(grad_out * yhat)
+      }
     } else {
 #pragma unroll
       for (int t = 0; t < HT; ++t)
@@ -294,7 +316,19 @@ __global__ __launch_bounds__(BNT) void mlp_backward_data_kernel(const gnc_mlp_de
       }
     }
   }
-
+  if (b.ln_partial) {  // fold the four row groups (lanes with the same c4), then one row of partials per wave
+    float* dst = b.ln_partial + (int64_t)((int)blockIdx.x * BWAVES + wave) * 2 * out_dim;
+    const float sg[4] = {add_quarters(sum_g.x), add_quarters(sum_g.y), add_quarters(sum_g.z), add_quarters(sum_g.w)};
+    const float sy[4] = {add_quarters(sum_gy.x), add_quarters(sum_gy.y), add_quarters(sum_gy.z), add_quarters(sum_gy.w)};
+    if (rs == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (c4 * 4 + k < out_dim) {
+          dst[c4 * 4 + k] = sg[k];
+          dst[out_dim + c4 * 4 + k] = sy[k];
+        }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -940,7 +974,8 @@ extern "C" int gnc_mlp_backward_f32(const gnc_mlp_bwd_desc_t* bd, void* stream_)
     GNC_REQUIRE(l == L - 1 || bd->act[l], "gnc_mlp_backward_f32: act[%d] is null", l);
   }
   const int grid = bwd_grid(d.rows);
-  GNC_REQUIRE(!d.ln_gamma || bd->yhat, "gnc_mlp_backward_f32: yhat is required with LayerNorm");
+  GNC_REQUIRE(!d.ln_gamma || bd->yhat || (resident && bd->ln_partial),
+              "gnc_mlp_backward_f32: with LayerNorm either yhat or (weights-resident shapes) ln_partial is required");
   GNC_REQUIRE(!bd->dx || bd->ld_dx >= d.in_dim[0], "gnc_mlp_backward_f32: ld_dx < in_dim[0]");
 
   BwdArgs b = {};
@@ -951,6 +986,7 @@ extern "C" int gnc_mlp_backward_f32(const gnc_mlp_bwd_desc_t* bd, void* stream_)
   b.ld_dx = bd->ld_dx;
   b.yhat = d.ln_gamma ? bd->yhat : nullptr;
   b.dx_add_grad_out = (resident && bd->dx_add_grad_out) ? 1 : 0;
+  b.ln_partial = (resident && d.ln_gamma) ? bd->ln_partial : nullptr;
 
   if (!resident) {
     hipStream_t st = (hipStream_t)stream_;
@@ -977,6 +1013,13 @@ extern "C" int gnc_mlp_backward_f32(const gnc_mlp_bwd_desc_t* bd, void* stream_)
   if (nmm == 2) GNC_BWD(1, 2, 0);
   GNC_BWD(1, 3, 0);
 #undef GNC_BWD
+}
+
+extern "C" int gnc_mlp_backward_ln_partial_rows(const gnc_mlp_desc_t* fwd) {
+  if (!fwd || gnc_mlp::validate_desc(fwd, false) != GNC_OK || !fwd->ln_gamma) return 0;
+  int nmm = 0, nadd = 0, T = 0;
+  if (!bwd_shape(*fwd, &nmm, &nadd, &T)) return 0;  // in-flight sums: the weights-resident data kernel only
+  return bwd_grid(fwd->rows) * BWAVES;
 }
 
 extern "C" int gnc_xty_partials(int64_t rows) {

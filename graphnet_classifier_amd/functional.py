@@ -167,7 +167,7 @@ def _fused_mlp_backward_hip(meta: _MlpMeta, args, need, grad_out):
         grads[s + l + k] = db if need[s + l + k] else None
     pos = s + 2 * l
     if meta.has_ln:
-        dbeta, dgamma = native.colsum_pair(grad_out, r["yhat"])
+        dbeta, dgamma = r["ln_sums"] if r["ln_sums"] is not None else native.colsum_pair(grad_out, r["yhat"])
         grads[pos] = dgamma if need[pos] else None
         grads[pos + 1] = dbeta if need[pos + 1] else None
         pos += 2
@@ -308,7 +308,7 @@ def _edge_wsplit_backward_hip(ctx, grad_out):
         grads[2 + k] = dw
         grads[2 + num_linear + k] = db
     if has_ln:
-        dbeta, dgamma = native.colsum_pair(grad_out, r["yhat"])
+        dbeta, dgamma = r["ln_sums"] if r["ln_sums"] is not None else native.colsum_pair(grad_out, r["yhat"])
         grads[2 + 2 * num_linear] = dgamma
         grads[2 + 2 * num_linear + 1] = dbeta
     return tuple(g if n else None for g, n in zip(grads, need))

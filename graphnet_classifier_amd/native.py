@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 GNC_MAX_SEGMENTS = 4
 GNC_MAX_LINEAR = 8
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 ACTIVATIONS = {  # nn.<Name> accepted by the reference's MLP(activation=...) (models/MLP.py:21)
     "ReLU": 0, "Identity": 1, "Tanh": 2, "Sigmoid": 3, "SiLU": 4, "GELU": 5, "LeakyReLU": 6, "ELU": 7,
@@ -49,6 +49,7 @@ _SIGNATURES = {
     "gnc_sizeof_mlp_bwd_desc": (c_size_t, []),
     "gnc_mlp_backward_supported": (c_int32, [c_void_p]),
     "gnc_mlp_backward_dx_add_honoured": (c_int32, [c_void_p]),
+    "gnc_mlp_backward_ln_partial_rows": (c_int32, [c_void_p]),
     "gnc_mlp_backward_f32": (c_int32, [c_void_p, c_void_p]),
     "gnc_xty_partials": (c_int32, [c_int64]),
     "gnc_xty_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, c_void_p, c_int32, c_void_p]),
@@ -88,7 +89,7 @@ class MlpBwdDesc(Structure):
     _fields_ = [
         ("fwd", MlpDesc), ("grad_out", c_void_p), ("ld_grad_out", c_int32),
         ("act", c_void_p * GNC_MAX_LINEAR), ("dz", c_void_p * GNC_MAX_LINEAR),
-        ("dx", c_void_p), ("ld_dx", c_int32), ("yhat", c_void_p), ("dx_add_grad_out", c_int32),
+        ("dx", c_void_p), ("ld_dx", c_int32), ("yhat", c_void_p), ("dx_add_grad_out", c_int32), ("ln_partial", c_void_p),
     ]
 
 
@@ -483,14 +484,25 @@ def mlp_backward(segments, weights, biases, ln, grad_out: torch.Tensor, rows: in
     dx = torch.empty(rows, w[0].size(1), dtype=torch.float32, device=dev) if need_dx else None
     if dx is not None:
         bd.dx, bd.ld_dx = dx.data_ptr(), _ld(dx)
-    yhat = torch.empty(rows, w[-1].size(0), dtype=torch.float32, device=dev) if ln is not None else None
-    if yhat is not None:
-        bd.yhat = yhat.data_ptr()
+    yhat = ln_part = None
+    if ln is not None:
+        prow = lib.gnc_mlp_backward_ln_partial_rows(ctypes.byref(bd.fwd))
+        if prow > 0:  # d gamma / d beta sums formed inside the data kernel: no y_hat tensor, no colsum pass
+            ln_part = torch.empty(prow, 2 * w[-1].size(0), dtype=torch.float32, device=dev)
+            bd.ln_partial = ln_part.data_ptr()
+        else:
+            yhat = torch.empty(rows, w[-1].size(0), dtype=torch.float32, device=dev)
+            bd.yhat = yhat.data_ptr()
     flops = 2.0 * rows * (2 * sum(x.size(0) * x.size(1) for x in w))
     with torch.cuda.device(dev):
         _check(_launch(f"mlp_backward_in{w[0].size(1)}_h{w[0].size(0)}_out{w[-1].size(0)}_L{n_lin}", g,
                        lambda: lib.gnc_mlp_backward_f32(ctypes.byref(bd), _stream(g)), flops), "gnc_mlp_backward_f32")
-    return {"act": act, "dz": dz, "dx": dx, "yhat": yhat, "residual_folded": bool(fold), "_keep": (segs, w, b, g)}
+    ln_sums = None
+    if ln_part is not None:
+        tot = ln_part.sum(dim=0)  # fixed order: reproducible
+        ln_sums = (tot[:w[-1].size(0)], tot[w[-1].size(0):])  # (d beta, d gamma)
+    return {"act": act, "dz": dz, "dx": dx, "yhat": yhat, "ln_sums": ln_sums, "residual_folded": bool(fold),
+            "_keep": (segs, w, b, g)}
 
 
 def xty(a: torch.Tensor, b: torch.Tensor):

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GNC_ABI_VERSION 10
+#define GNC_ABI_VERSION 11
 
 enum {
   GNC_OK = 0,
@@ -240,11 +240,17 @@ typedef struct gnc_mlp_bwd_desc {
   int32_t dx_add_grad_out; /* 1: the LAST MATMUL segment is also the residual and out_dim equals its width: its dx
                               columns get grad_out added in the kernel (honoured by the weights-resident variant;
                               gnc_mlp_backward_dx_add_honoured() tells) */
+  float* ln_partial;       /* NULL, or [gnc_mlp_backward_ln_partial_rows(fwd), 2 * out_dim]: row w receives
+                              [ colsum(grad_out) | colsum(grad_out * yhat) ] over the rows wave w processed (sum the
+                              rows in order: d beta, d gamma).  With it `yhat` is neither needed nor written and
+                              gnc_colsum_pair_f32 is not needed: 3 x [rows, out_dim] of HBM traffic less per launch. */
 } gnc_mlp_bwd_desc_t;
 
 size_t gnc_sizeof_mlp_bwd_desc(void);
 int gnc_mlp_backward_supported(const gnc_mlp_desc_t* fwd /* host */);
 int gnc_mlp_backward_dx_add_honoured(const gnc_mlp_desc_t* fwd /* host */); /* 1 / 0 */
+/* rows of `ln_partial` this description needs, 0 if its backward kernel cannot form the LayerNorm sums in flight */
+int gnc_mlp_backward_ln_partial_rows(const gnc_mlp_desc_t* fwd /* host */);
 int gnc_mlp_backward_f32(const gnc_mlp_bwd_desc_t* desc /* host */, void* stream);
 int gnc_xty_partials(int64_t rows);
 int gnc_xty_f32(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t rows, int32_t M, int32_t K,
