@@ -182,10 +182,10 @@ def main():
 
     # warm-up steps run exactly like timed ones (per-launch HIP events included), so that nothing - event pools,
     # allocator blocks, lazily loaded code objects - is created for the first time inside the timed region
-    native.set_kernel_timers(native.KernelTimers())
-    # device pre-heat (untimed, before the W warm-up steps): on a cold box the first ~0.1-0.3 s of sustained load
-    # contain one 40-60 ms stall (seen on every fresh MI355X box, in whichever step falls there), presumably
-    # the power controller settling; it must not land in the K timed steps
+    warm_timers = native.KernelTimers()
+    native.set_kernel_timers(warm_timers)
+    # device pre-heat (untimed, before the W warm-up steps): clocks and caches settle, and the HIP runtime's
+    # event / signal pools grow here instead of inside the K timed steps
     if a.preheat_ms > 0:
         t_heat = time.perf_counter()
         y = step()
@@ -201,9 +201,16 @@ def main():
         y = step()
         torch.cuda.Event(enable_timing=True).record()
     timers = native.KernelTimers()
+    # every HIP event of the timed region exists before it starts (see KernelTimers.reserve)
+    steps_seen = max(1, a.warmup + (int(n_heat.item()) + 1 if a.preheat_ms > 0 else 0))
+    timers.reserve(int(warm_timers.num_launches() / steps_seen * (a.steps + 1) * 1.1) + 64)
+    del warm_timers
     native.set_kernel_timers(timers)
     fence()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]  # per-step spread (diagnostic only)
+    for ev in marks:
+        ev.record()  # allocate them now (re-recorded below)
+    allocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)  # hipMalloc calls of the caching allocator so far
     t0 = time.perf_counter()
     marks[0].record()
     for k in range(a.steps):
@@ -211,6 +218,7 @@ def main():
         marks[k + 1].record()
     fence()
     elapsed = time.perf_counter() - t0
+    device_allocs_timed = torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - allocs0
     per_step_order = [marks[k].elapsed_time(marks[k + 1]) for k in range(a.steps)]
     per_step = sorted(per_step_order)
     # (not part of `value`) the same step with the topology cached: SURVEY 8d asks for the throughput with and
@@ -297,7 +305,8 @@ def main():
                              "reference_form_flops_per_launch": mlp["avg_work"] + (4.0 * batch.num_edges * w["width"] ** 2
                                                                                     if "+2add" in mlp_name else 0.0)},
             "step_ms_spread": {"min": per_step[0], "median": per_step[len(per_step) // 2], "max": per_step[-1],
-                               "slowest_step": per_step_order.index(per_step[-1])},
+                               "slowest_step": per_step_order.index(per_step[-1]),
+                               "device_allocs_in_timed_region": device_allocs_timed},
             "kernel_ms_per_step": {k: v["avg_ms"] * v["launches"] / a.steps for k, v in ksum.items()
                                    if not (k1_isolated and k.startswith("scatter_sum_csr"))},
         }
