@@ -332,6 +332,253 @@ __global__ __launch_bounds__(BNT) void mlp_backward_data_kernel(const gnc_mlp_de
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Fused variant for the shape that dominates training (widths 33..64, three Linear layers, ONE row-ordered
+// MATMUL segment that may also be the residual, plus 0 or 2 gathered ADD segments): the weight gradients are
+// formed in the same kernel.  dW_l = dz_l^T a_{l-1} needs both operands of a tile with the rows on the MFMA k
+// axis; both sit in the wave's LDS tiles anyway, so the outer products are accumulated in registers for the whole
+// life of the wave (3 x 64 registers) and leave as ONE row of partials per wave and layer (same layout and fixed-
+// order reduction as gnc_xty_f32).  Nothing but dz_0 (the ADD segments' gradient), dx and the partials is written:
+// the a_l / dz_l / y_hat tensors of the split path (6 x [rows, 64] written here, read back by xty / colsum) do not
+// exist.  4 waves per CU, one per SIMD, with the 512-register budget that takes.
+// ---------------------------------------------------------------------------------------------------
+constexpr int FWAVES = 4;
+constexpr int FNT = FWAVES * 64;
+
+struct FusedOut {
+  float* dw[3];   // per-wave partials [waves, M_l * K_l + M_l]: [dW_l row-major | db_l]
+  int M[3], K[3];
+};
+
+// acc[a][c] += sum over the tile's 32 rows of tm[row][32a + .] (x) tk[row][32c + .]; csum[a] += column sums of tm
+__device__ __forceinline__ void xty_tile(f32x16 (&acc)[2][2], float (&csum)[2], const float* tm, const float* tk, int i, int h) {
+#pragma unroll 4
+  for (int s = 0; s < RPW / 2; ++s) {
+    float av[2], bv[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      av[a] = tm[(2 * s + h) * LDSW + 32 * a + i];
+      csum[a] += av[a];
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) bv[c] = tk[(2 * s + h) * LDSW + 32 * c + i];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) acc[a][c] = mfma(av[a], bv[c], acc[a][c]);
+  }
+}
+
+template <int NADD>
+__global__ __launch_bounds__(FNT) void mlp_backward_fused_kernel(const gnc_mlp_desc_t d, const BwdArgs b, const FusedOut fo,
+                                                                 const int num_wtiles) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int HT = 2;
+  constexpr int CH = HT * 32 * LDSW;
+  constexpr int PSTRIDE = HT * 32;
+  constexpr int L = 3;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 31;
+  const int h = lane >> 5;
+  const int c4 = lane & 15;
+  const int rs = lane >> 4;
+  const int out_dim = d.out_dim[L - 1];
+  const int rows = (int)d.rows;
+  float* wres = lds;                                   // 3 weight chunks: W0 (its MATMUL columns), W1, W2
+  float* pbuf = lds + 3 * CH;                          // biases 0..2, gamma, beta
+  float* te = pbuf + (L + 2) * PSTRIDE + wave * 3 * RPW * LDSW;  // the tile's input rows (kept for dW0)
+  float* ta = te + RPW * LDSW;                         // working tile A
+  float* tb = ta + RPW * LDSW;                         // working tile B
+
+  stage_params<FNT>(pbuf, d, PSTRIDE, tid);
+  {
+    const int ldw0 = ldw_of(d, 0);
+    const bool w0v = (ldw0 % 4 == 0) && ((reinterpret_cast<uintptr_t>(d.weight[0]) & 15u) == 0) && (d.seg[0].wcol % 4 == 0);
+    stage_weights<HT * 32, FNT>(wres, d.weight[0], ldw0, d.out_dim[0], d.seg[0].wcol, d.seg[0].wcol + d.seg[0].width, 16, w0v, tid);
+    for (int l = 1; l < L; ++l) {
+      const int ldw = ldw_of(d, l);
+      const bool wv = (ldw % 4 == 0) && ((reinterpret_cast<uintptr_t>(d.weight[l]) & 15u) == 0);
+      stage_weights<HT * 32, FNT>(wres + l * CH, d.weight[l], ldw, d.out_dim[l], 0, d.in_dim[l], 16, wv, tid);
+    }
+  }
+  __syncthreads();
+
+  f32x16 dW0[2][2], dW1[2][2], dW2[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dW0[a][c][r] = dW1[a][c][r] = dW2[a][c][r] = 0.f;
+  float cs0[2] = {0.f, 0.f}, cs1[2] = {0.f, 0.f}, cs2[2] = {0.f, 0.f};
+  f32x4 sum_g = {0.f, 0.f, 0.f, 0.f}, sum_gy = {0.f, 0.f, 0.f, 0.f};
+
+  const gnc_mlp_segment_t& s0 = d.seg[0];
+  const uint32_t e_off = (uint32_t)(rs * s0.ld + (c4 * 4 < s0.ld ? c4 * 4 : 0)) * 4u;
+  const uint32_t g_off = (uint32_t)(rs * b.ld_grad_out + (c4 * 4 < out_dim ? c4 * 4 : 0)) * 4u;
+  const int total_waves = (int)gridDim.x * FWAVES;
+
+  auto to_tile = [&](float* t, const f32x4 (&pre)[NP], int width) {  // whole-row pieces -> LDS tile, zero beyond `width`
+    compiler_lds_barrier();
+    const int c = c4 * 4;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      f32x4 v = pre[p];
+      if (width < KC) {
+        v.x = c + 0 < width ? v.x : 0.f; v.y = c + 1 < width ? v.y : 0.f;
+        v.z = c + 2 < width ? v.z : 0.f; v.w = c + 3 < width ? v.w : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(t + (p * 4 + rs) * LDSW + c) = v;
+    }
+    compiler_lds_barrier();
+  };
+  auto acc_to_tile = [&](float* t, const f32x16 (&acc)[HT]) {
+    compiler_lds_barrier();
+    tiles_to_lds<HT>(acc, t, i, h);
+    compiler_lds_barrier();
+  };
+
+  for (int wt = (int)blockIdx.x * FWAVES + wave; wt < num_wtiles; wt += total_waves) {
+    const int row0 = wt * RPW;
+    // ---------------------------------------------------------------- the tile's rows
+    f32x4 pe[NP], pg[NP], pa[NADD ? NP : 1], pb[NADD ? NP : 1];
+    load_tile_rows(pe, s0.ptr, s0.ld, row0, rows, e_off);
+    load_tile_rows(pg, b.grad_out, b.ld_grad_out, row0, rows, g_off);
+    if constexpr (NADD > 0) {
+      int r = row0 + (lane & 31);
+      r = r < rows ? r : rows - 1;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const gnc_mlp_segment_t& sg = d.seg[1 + k];
+        const __amdgpu_buffer_rsrc_t w =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.ptr), 0, (int)(uint32_t)(sg.table_rows * sg.ld * 4), 0x00020000);
+        const int rb = sg.index[r] * (sg.ld * 4);
+        const uint32_t col = (uint32_t)(c4 * 4 < sg.ld ? c4 * 16 : 0);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const f32x4 v = window_load(w, (uint32_t)__shfl(rb, p * 4 + rs, 64) + col);
+          if (k == 0) pa[p] = v; else pb[p] = v;
+        }
+      }
+    }
+    // ---------------------------------------------------------------- forward recompute
+    to_tile(te, pe, s0.width);
+    f32x16 a0[HT];
+    init_bias<HT>(a0, pbuf, h);
+    mma_chunk_from_lds<HT>(a0, te, wres, (s0.width + 7) >> 3, i, h);
+    if constexpr (NADD > 0) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) pa[p] += pb[p];
+      to_tile(ta, pa, d.seg[1].width);
+      add_tile_from_lds<HT>(a0, ta, i, h);
+    }
+    const unsigned m0 = relu_tiles_mask<HT>(a0);
+    f32x16 a1[HT];
+    init_bias<HT>(a1, pbuf + PSTRIDE, h);
+    mma_chunk_from_regs<HT, HT>(a1, a0, wres + CH, 0, d.in_dim[1], i, h);
+    const unsigned m1 = relu_tiles_mask<HT>(a1);
+    // ---------------------------------------------------------------- grad of the pre-LayerNorm output
+    f32x16 g[HT];
+    to_tile(tb, pg, out_dim);
+    tile_from_lds<HT>(g, tb, i, h);
+    if (d.ln_gamma) {
+      f32x16 y[HT];
+      init_bias<HT>(y, pbuf + 2 * PSTRIDE, h);
+      mma_chunk_from_regs<HT, HT>(y, a1, wres + 2 * CH, 0, d.in_dim[2], i, h);
+      layer_norm_backward_tiles<HT>(y, g, pbuf + L * PSTRIDE, out_dim, d.ln_eps, h);
+      acc_to_tile(tb, y);  // y_hat as whole rows: the LayerNorm parameter sums (grad_out's pieces are still in pg)
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const f32x4 yh = *reinterpret_cast<const f32x4*>(tb + (p * 4 + rs) * LDSW + c4 * 4);
+        sum_g += pg[p];
+        sum_gy = __builtin_elementwise_fma(pg[p], yh, sum_gy);
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < HT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[t][r] = (feat_of(t, r, h) < out_dim) ? g[t][r] : 0.f;
+    }
+    // ---------------------------------------------------------------- layer 2: dW2 += dz2^T a1, da1 = W2^T dz2
+    acc_to_tile(tb, g);
+    acc_to_tile(ta, a1);
+    xty_tile(dW2, cs2, tb, ta, i, h);
+    {
+      f32x16 da[HT];
+      zero_tiles<HT>(da);
+      mma_transposed_from_regs<HT, HT>(da, g, wres + 2 * CH, i, h);
+      apply_mask<HT>(da, m1);
+#pragma unroll
+      for (int t = 0; t < HT; ++t) g[t] = da[t];
+    }
+    // ---------------------------------------------------------------- layer 1
+    acc_to_tile(tb, g);
+    acc_to_tile(ta, a0);
+    xty_tile(dW1, cs1, tb, ta, i, h);
+    {
+      f32x16 da[HT];
+      zero_tiles<HT>(da);
+      mma_transposed_from_regs<HT, HT>(da, g, wres + CH, i, h);
+      apply_mask<HT>(da, m0);
+#pragma unroll
+      for (int t = 0; t < HT; ++t) g[t] = da[t];
+    }
+    // ---------------------------------------------------------------- layer 0: dW0 += dz0^T e, dz0 out, dx
+    acc_to_tile(tb, g);
+    xty_tile(dW0, cs0, tb, te, i, h);
+    if (b.dz[0]) store_staged_rows(tb, b.dz[0], d.out_dim[0], d.out_dim[0], row0, rows, c4, rs);
+    if (b.dx) {
+      f32x16 dxs[HT];
+      zero_tiles<HT>(dxs);
+      mma_transposed_from_regs<HT, HT>(dxs, g, wres, i, h);
+      acc_to_tile(ta, dxs);
+      store_staged_rows(ta, b.dx + s0.wcol, b.ld_dx, s0.width, row0, rows, c4, rs, b.dx_add_grad_out ? b.grad_out : nullptr,
+                        b.ld_grad_out);
+    }
+    compiler_lds_barrier();
+  }
+
+  // ------------------------------------------------------------------ one row of partials per wave and layer
+  const int gw = (int)blockIdx.x * FWAVES + wave;
+  auto write_partial = [&](int l, const f32x16 (&acc)[2][2], const float (&cs)[2]) {
+    const int M = fo.M[l], K = fo.K[l];
+    float* dst = fo.dw[l] + (int64_t)gw * (M * K + M);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const int k = 32 * c + i;
+          if (m < M && k < K) dst[m * K + k] = acc[a][c][r];
+        }
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const float tot = add_halves(cs[a]);
+      if (h == 0 && 32 * a + i < M) dst[M * K + 32 * a + i] = tot;
+    }
+  };
+  write_partial(0, dW0, cs0);
+  write_partial(1, dW1, cs1);
+  write_partial(2, dW2, cs2);
+  if (b.ln_partial) {
+    float* dst = b.ln_partial + (int64_t)gw * 2 * out_dim;
+    const float sg[4] = {add_quarters(sum_g.x), add_quarters(sum_g.y), add_quarters(sum_g.z), add_quarters(sum_g.w)};
+    const float sy[4] = {add_quarters(sum_gy.x), add_quarters(sum_gy.y), add_quarters(sum_gy.z), add_quarters(sum_gy.w)};
+    if (rs == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (c4 * 4 + k < out_dim) {
+          dst[c4 * 4 + k] = sg[k];
+          dst[out_dim + c4 * 4 + k] = sy[k];
+        }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Streamed variant of the data kernel for widths 65..128: the weights do not fit in LDS, so the chunk
 // sequence of a tile - forward chunks, then the SAME [features][64 k] chunks again in reverse layer order
 // for the transposed products - streams through the double buffer of mlp_stream.hip (registers ->
@@ -954,6 +1201,44 @@ extern "C" int gnc_mlp_backward_dx_add_honoured(const gnc_mlp_desc_t* fwd) {
   return (fwd && validate_desc(fwd, false) == GNC_OK && bwd_shape(*fwd, &nmm, &nadd, &T)) ? 1 : 0;
 }
 
+namespace {
+// shape of the fused data + weight-gradient kernel; returns the number of ADD segments (0 / 2) or -1
+int fused_shape(const gnc_mlp_desc_t& d) {
+  if (d.num_linear != 3 || d.activation != GNC_ACT_RELU || d.rows < 1 || d.rows >= INT32_MAX - (1 << 22)) return -1;
+  for (int l = 0; l < 3; ++l)
+    if (d.out_dim[l] > KC || (l > 0 && d.in_dim[l] > KC)) return -1;
+  if (d.num_segments != 1 && d.num_segments != 3) return -1;
+  const gnc_mlp_segment_t& s0 = d.seg[0];
+  if (s0.mode != GNC_SEG_MATMUL || s0.index || s0.width > KC || s0.ld % 4 != 0 || !al16(s0.ptr)) return -1;
+  for (int s = 1; s < d.num_segments; ++s) {
+    const gnc_mlp_segment_t& g = d.seg[s];
+    if (g.mode != GNC_SEG_ADD || !g.index || g.width > KC || g.ld % 4 != 0 || !al16(g.ptr)) return -1;
+    if (g.table_rows <= 0 || g.table_rows * (int64_t)g.ld * 4 > 0xffffffffll) return -1;
+  }
+  return d.num_segments - 1;
+}
+int fused_grid(int64_t rows) {
+  const int64_t grid = gnc::ceil_div(gnc::ceil_div(rows, RPW), FWAVES);
+  return (int)(grid > gnc::kNumCU ? gnc::kNumCU : grid);
+}
+constexpr size_t kFusedSmem = ((size_t)3 * 2 * 32 * LDSW + (size_t)5 * 64 + (size_t)FWAVES * 3 * RPW * LDSW) * sizeof(float);
+
+template <int NADD>
+int launch_fused(const gnc_mlp_desc_t& d, const BwdArgs& b, const FusedOut& fo, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    int rc = gnc::check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_backward_fused_kernel<NADD>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                            "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    if (rc) return rc;
+    attr_set = true;
+  }
+  const int64_t num_wtiles = gnc::ceil_div(d.rows, RPW);
+  mlp_backward_fused_kernel<NADD><<<dim3((unsigned)fused_grid(d.rows)), dim3(FNT), kFusedSmem, stream>>>(d, b, fo, (int)num_wtiles);
+  return gnc::check_launch("mlp_backward_fused_kernel");
+}
+}  // namespace
+
 extern "C" int gnc_mlp_backward_f32(const gnc_mlp_bwd_desc_t* bd, void* stream_) {
   if (!bd) { gnc::set_error("gnc_mlp_backward_f32: null descriptor"); return GNC_ERR_INVALID_ARGUMENT; }
   const gnc_mlp_desc_t& d = bd->fwd;
@@ -961,6 +1246,30 @@ extern "C" int gnc_mlp_backward_f32(const gnc_mlp_bwd_desc_t* bd, void* stream_)
   if (rc) return rc;
   int nmm = 0, nadd = 0, T = 0;
   BwdPlan pl;
+  if (bd->dw_partial[0]) {  // fused data + weight-gradient kernel
+    const int fn = fused_shape(d);
+    if (fn < 0) { gnc::set_error("gnc_mlp_backward_f32: dw_partial given but the shape is outside the fused kernel"); return GNC_ERR_UNSUPPORTED; }
+    GNC_REQUIRE(bd->dw_partial[1] && bd->dw_partial[2], "gnc_mlp_backward_f32: dw_partial[0..2] must all be given");
+    GNC_REQUIRE(!d.ln_gamma || bd->ln_partial, "gnc_mlp_backward_f32: the fused kernel needs ln_partial with LayerNorm");
+    GNC_REQUIRE(bd->grad_out && bd->ld_grad_out % 4 == 0 && al16(bd->grad_out) && bd->ld_grad_out >= d.out_dim[2],
+                "gnc_mlp_backward_f32: grad_out must be 16-B aligned with ld %% 4 == 0");
+    GNC_REQUIRE(!bd->dx || bd->ld_dx >= d.in_dim[0], "gnc_mlp_backward_f32: ld_dx < in_dim[0]");
+    BwdArgs fb = {};
+    fb.grad_out = bd->grad_out;
+    fb.ld_grad_out = bd->ld_grad_out;
+    fb.dz[0] = bd->dz[0];
+    fb.dx = bd->dx;
+    fb.ld_dx = bd->ld_dx;
+    fb.dx_add_grad_out = bd->dx_add_grad_out ? 1 : 0;
+    fb.ln_partial = d.ln_gamma ? bd->ln_partial : nullptr;
+    FusedOut fo = {};
+    for (int l = 0; l < 3; ++l) {
+      fo.dw[l] = bd->dw_partial[l];
+      fo.M[l] = d.out_dim[l];
+      fo.K[l] = l == 0 ? d.seg[0].width : d.in_dim[l];
+    }
+    return fn == 2 ? launch_fused<2>(d, fb, fo, (hipStream_t)stream_) : launch_fused<0>(d, fb, fo, (hipStream_t)stream_);
+  }
   const bool resident = bwd_shape(d, &nmm, &nadd, &T);
   if (!resident && !bwd_stream_plan(d, bd->dx != nullptr, &pl, &T)) {
     gnc::set_error("gnc_mlp_backward_f32: shape outside the HIP backward kernels");
@@ -1013,6 +1322,13 @@ extern "C" int gnc_mlp_backward_f32(const gnc_mlp_bwd_desc_t* bd, void* stream_)
   if (nmm == 2) GNC_BWD(1, 2, 0);
   GNC_BWD(1, 3, 0);
 #undef GNC_BWD
+}
+
+extern "C" int gnc_mlp_backward_fused_rows(const gnc_mlp_desc_t* fwd) {
+  static const bool off = getenv("GNC_NO_FUSED_BACKWARD") != nullptr;  // A/B switch
+  if (off || !fwd || gnc_mlp::validate_desc(fwd, false) != GNC_OK || fused_shape(*fwd) < 0) return 0;
+  static_assert(kFusedSmem <= 160 * 1024, "fused backward kernel: LDS budget");
+  return fused_grid(fwd->rows) * FWAVES;
 }
 
 extern "C" int gnc_mlp_backward_ln_partial_rows(const gnc_mlp_desc_t* fwd) {

@@ -153,6 +153,10 @@ def _fused_mlp_backward_hip(meta: _MlpMeta, args, need, grad_out):
     for k in range(l):
         if not (need[s + k] or need[s + l + k]):
             continue
+        if "dw" in r:  # fused kernel: weight gradients came out of the data kernel (single row-ordered segment)
+            grads[s + k] = r["dw"][k] if need[s + k] else None
+            grads[s + l + k] = r["db"][k] if need[s + l + k] else None
+            continue
         dz = r["dz"][k]
         if k == 0:
             parts, db = [], None
@@ -300,11 +304,11 @@ def _edge_wsplit_backward_hip(ctx, grad_out):
     if need[2] or need[2 + num_linear]:
         dws, _ = native.xty(dps, x)
         dwd, _ = native.xty(dpd, x)
-        dwe, db0 = native.xty(dz0, e)
+        dwe, db0 = (r["dw"][0], r["db"][0]) if "dw" in r else native.xty(dz0, e)
         grads[2] = torch.cat([dws, dwd, dwe], dim=1)
         grads[2 + num_linear] = db0
     for k in range(1, num_linear):
-        dw, db = native.xty(r["dz"][k], r["act"][k - 1])
+        dw, db = (r["dw"][k], r["db"][k]) if "dw" in r else native.xty(r["dz"][k], r["act"][k - 1])
         grads[2 + k] = dw
         grads[2 + num_linear + k] = db
     if has_ln:

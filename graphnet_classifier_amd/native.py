@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 GNC_MAX_SEGMENTS = 4
 GNC_MAX_LINEAR = 8
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 ACTIVATIONS = {  # nn.<Name> accepted by the reference's MLP(activation=...) (models/MLP.py:21)
     "ReLU": 0, "Identity": 1, "Tanh": 2, "Sigmoid": 3, "SiLU": 4, "GELU": 5, "LeakyReLU": 6, "ELU": 7,
@@ -50,6 +50,7 @@ _SIGNATURES = {
     "gnc_mlp_backward_supported": (c_int32, [c_void_p]),
     "gnc_mlp_backward_dx_add_honoured": (c_int32, [c_void_p]),
     "gnc_mlp_backward_ln_partial_rows": (c_int32, [c_void_p]),
+    "gnc_mlp_backward_fused_rows": (c_int32, [c_void_p]),
     "gnc_mlp_backward_f32": (c_int32, [c_void_p, c_void_p]),
     "gnc_xty_partials": (c_int32, [c_int64]),
     "gnc_xty_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, c_void_p, c_int32, c_void_p]),
@@ -90,6 +91,7 @@ class MlpBwdDesc(Structure):
         ("fwd", MlpDesc), ("grad_out", c_void_p), ("ld_grad_out", c_int32),
         ("act", c_void_p * GNC_MAX_LINEAR), ("dz", c_void_p * GNC_MAX_LINEAR),
         ("dx", c_void_p), ("ld_dx", c_int32), ("yhat", c_void_p), ("dx_add_grad_out", c_int32), ("ln_partial", c_void_p),
+        ("dw_partial", c_void_p * GNC_MAX_LINEAR),
     ]
 
 
@@ -471,10 +473,12 @@ def mlp_backward_supported(segments, weights, biases, ln, activation, residual, 
 
 
 def mlp_backward(segments, weights, biases, ln, grad_out: torch.Tensor, rows: int | None = None, modes=None,
-                 need_dx: bool = True, residual: torch.Tensor | None = None):
+                 need_dx: bool = True, residual: torch.Tensor | None = None, fused: bool = True):
     """Data path of the MLP backward (see include/gnc_hip.h, K8).  Returns a dict with
     ``act`` (inputs of Linear 1..L-1), ``dz`` (grads of every pre-activation, dz[-1] = pre-LayerNorm),
-    ``dx`` ([rows, in_dim0] in weight-column order, or None) and ``yhat`` (or None)."""
+    ``dx`` ([rows, in_dim0] in weight-column order, or None) and ``yhat`` (or None).  Shapes of the fused kernel
+    (``fused=True`` and gnc_mlp_backward_fused_rows() > 0) return ``dw`` / ``db`` (one per Linear; ``dw[0]`` covers the
+    columns of the MATMUL segment) instead of ``act`` / ``dz[1:]``."""
     lib = load_library()
     segs, w, b, residual, rows, _ = _prepare_mlp(segments, weights, biases, residual, rows, modes)
     dev = segs[0][0].device
@@ -489,6 +493,41 @@ def mlp_backward(segments, weights, biases, ln, grad_out: torch.Tensor, rows: in
     g = _vector_rows(_rowmajor(grad_out))
     bd.grad_out, bd.ld_grad_out = g.data_ptr(), _ld(g)
     n_lin = len(w)
+    frows = lib.gnc_mlp_backward_fused_rows(ctypes.byref(bd.fwd)) if fused else 0
+    if frows > 0:
+        # fused data + weight-gradient kernel: per-wave partials of dW_l / db_l (and of the LayerNorm sums) instead of
+        # the a_l / dz_l / y_hat tensors; only dz_0 (gradient of gathered ADD segments) and dx are written
+        bd.dx_add_grad_out = 1 if (residual is not None and need_dx and mm[-1][1] is None
+                                   and mm[-1][0].data_ptr() == residual.data_ptr() and mm[-1][2] == w[-1].size(0)) else 0
+        mk = [(w[l].size(0), w[l].size(1)) for l in range(n_lin)]
+        parts = [torch.empty(frows, m * k + m, dtype=torch.float32, device=dev) for m, k in mk]
+        for l in range(n_lin):
+            bd.dw_partial[l] = parts[l].data_ptr()
+        dz0 = torch.empty(rows, w[0].size(0), dtype=torch.float32, device=dev) if len(segs) > 1 else None
+        if dz0 is not None:
+            bd.dz[0] = dz0.data_ptr()
+        dx = torch.empty(rows, w[0].size(1), dtype=torch.float32, device=dev) if need_dx else None
+        if dx is not None:
+            bd.dx, bd.ld_dx = dx.data_ptr(), _ld(dx)
+        ln_part = None
+        if ln is not None:
+            ln_part = torch.empty(frows, 2 * w[-1].size(0), dtype=torch.float32, device=dev)
+            bd.ln_partial = ln_part.data_ptr()
+        flops = 2.0 * rows * (3 * sum(x.size(0) * x.size(1) for x in w))
+        with torch.cuda.device(dev):
+            _check(_launch(f"mlp_backward_fused_in{w[0].size(1)}_h{w[0].size(0)}_out{w[-1].size(0)}_L{n_lin}", g,
+                           lambda: lib.gnc_mlp_backward_f32(ctypes.byref(bd), _stream(g)), flops), "gnc_mlp_backward_f32")
+        dws, dbs = [], []
+        for (m, k), part in zip(mk, parts):
+            tot = part.sum(dim=0)  # fixed order: reproducible
+            dws.append(tot[:m * k].view(m, k))
+            dbs.append(tot[m * k:])
+        ln_sums = None
+        if ln_part is not None:
+            tot = ln_part.sum(dim=0)
+            ln_sums = (tot[:w[-1].size(0)], tot[w[-1].size(0):])
+        return {"act": None, "dz": [dz0] + [None] * (n_lin - 1), "dx": dx, "yhat": None, "ln_sums": ln_sums, "dw": dws, "db": dbs,
+                "residual_folded": bool(bd.dx_add_grad_out), "_keep": (segs, w, b, g)}
     act = [torch.empty(rows, w[l].size(0), dtype=torch.float32, device=dev) for l in range(n_lin - 1)]
     dz = [torch.empty(rows, w[l].size(0), dtype=torch.float32, device=dev) for l in range(n_lin)]
     for l in range(n_lin):

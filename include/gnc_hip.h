@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GNC_ABI_VERSION 11
+#define GNC_ABI_VERSION 12
 
 enum {
   GNC_OK = 0,
@@ -244,6 +244,11 @@ typedef struct gnc_mlp_bwd_desc {
                               [ colsum(grad_out) | colsum(grad_out * yhat) ] over the rows wave w processed (sum the
                               rows in order: d beta, d gamma).  With it `yhat` is neither needed nor written and
                               gnc_colsum_pair_f32 is not needed: 3 x [rows, out_dim] of HBM traffic less per launch. */
+  float* dw_partial[GNC_MAX_LINEAR]; /* all NULL, or for l < num_linear: [gnc_mlp_backward_fused_rows(fwd), M_l*K_l + M_l]
+                              with M_l = out_dim[l], K_l = in_dim[l] (l = 0: the width of the MATMUL segment): row w
+                              receives [ dW_l row-major | db_l ] over the rows wave w processed - the layout of
+                              gnc_xty_f32, formed INSIDE the data kernel.  With it act[], dz[1..], yhat are neither
+                              needed nor written (dz[0] still is when given); ln_partial is required with LayerNorm. */
 } gnc_mlp_bwd_desc_t;
 
 size_t gnc_sizeof_mlp_bwd_desc(void);
@@ -251,6 +256,10 @@ int gnc_mlp_backward_supported(const gnc_mlp_desc_t* fwd /* host */);
 int gnc_mlp_backward_dx_add_honoured(const gnc_mlp_desc_t* fwd /* host */); /* 1 / 0 */
 /* rows of `ln_partial` this description needs, 0 if its backward kernel cannot form the LayerNorm sums in flight */
 int gnc_mlp_backward_ln_partial_rows(const gnc_mlp_desc_t* fwd /* host */);
+/* rows of `dw_partial[l]` (and then also of `ln_partial`) if this description can run the fused data + weight-
+ * gradient kernel (three Linear layers, widths <= 64, one row-ordered MATMUL segment and 0 or 2 gathered ADD
+ * segments with stated tables), else 0 */
+int gnc_mlp_backward_fused_rows(const gnc_mlp_desc_t* fwd /* host */);
 int gnc_mlp_backward_f32(const gnc_mlp_bwd_desc_t* desc /* host */, void* stream);
 int gnc_xty_partials(int64_t rows);
 int gnc_xty_f32(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t rows, int32_t M, int32_t K,

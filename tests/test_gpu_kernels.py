@@ -450,9 +450,11 @@ def _torch_mlp(sd, x_cat, residual=None):
     ((128,), 128, 1, 2, False, False),
     ((96, 40), 100, 72, 3, True, False),
 ])
-def test_mlp_backward_kernel_matches_autograd(native, in_dims, hidden, out_dim, hl, ln, res):
+@pytest.mark.parametrize("fused", [False, True])
+def test_mlp_backward_kernel_matches_autograd(native, in_dims, hidden, out_dim, hl, ln, res, fused):
     """dz / act / dx / yhat of the K8 data kernel and the xty weight gradients against torch.autograd
-    of the same MLP in float64."""
+    of the same MLP in float64; ``fused``: weight gradients from the fused data + weight-gradient kernel where the
+    shape allows it (three Linear layers, one row-ordered segment, widths <= 64)."""
     rng = np.random.default_rng(sum(in_dims) + hidden + out_dim)
     rows = 1000
     in_dim = sum(in_dims)
@@ -472,15 +474,18 @@ def test_mlp_backward_kernel_matches_autograd(native, in_dims, hidden, out_dim, 
     lnp = (sd[lnk[0]].to(DEV), sd[lnk[0].replace("weight", "bias")].to(DEV), 1e-5) if lnk else None
     segs = [(t.to(DEV), None) for t in tabs]
     assert native.mlp_backward_supported(segs, ws, bs, lnp, "ReLU", residual.to(DEV) if res else None, rows)
-    r = native.mlp_backward(segs, ws, bs, lnp, gout.to(DEV), rows=rows, need_dx=True)
+    r = native.mlp_backward(segs, ws, bs, lnp, gout.to(DEV), rows=rows, need_dx=True, fused=fused)
     dx_ref = torch.cat([t.grad for t in t64], -1)
     if res:
         dx_ref[:, :in_dims[0]] -= gout.double()  # the kernel's dx excludes the residual path
     assert max_abs(r["dx"].cpu(), dx_ref.float()) < 2e-5
     lin_keys = sorted((k for k in sd if sd[k].ndim == 2), key=lambda k: int(k.split(".")[2]))
     for li, k in enumerate(lin_keys):
-        inp = torch.cat(tabs, -1).to(DEV) if li == 0 else r["act"][li - 1]
-        dw, db = native.xty(r["dz"][li], inp)
+        if "dw" in r:
+            dw, db = r["dw"][li], r["db"][li]
+        else:
+            inp = torch.cat(tabs, -1).to(DEV) if li == 0 else r["act"][li - 1]
+            dw, db = native.xty(r["dz"][li], inp)
         gw, gb = sd64[k].grad, sd64[k.replace("weight", "bias")].grad
         assert float((dw.cpu().double() - gw).abs().max()) < 1e-4 * max(1.0, float(gw.abs().max())), k
         assert float((db.cpu().double() - gb).abs().max()) < 1e-4 * max(1.0, float(gb.abs().max())), k
