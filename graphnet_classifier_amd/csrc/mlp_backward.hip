@@ -439,6 +439,17 @@ __global__ __launch_bounds__(FNT) void mlp_backward_fused_kernel(const gnc_mlp_d
     compiler_lds_barrier();
   };
 
+  // gather ids travel one tile ahead (two registers): the gathers of a tile then cost one memory round trip, not two
+  int ids_nxt[2] = {0, 0};
+  auto load_ids = [&](int wt_) {
+    if constexpr (NADD > 0) {
+      int r = wt_ * RPW + (lane & 31);
+      r = r < rows ? r : rows - 1;
+      ids_nxt[0] = d.seg[1].index[r];
+      ids_nxt[1] = d.seg[2].index[r];
+    }
+  };
+  load_ids((int)blockIdx.x * FWAVES + wave);
   for (int wt = (int)blockIdx.x * FWAVES + wave; wt < num_wtiles; wt += total_waves) {
     const int row0 = wt * RPW;
     // ---------------------------------------------------------------- the tile's rows
@@ -446,14 +457,13 @@ __global__ __launch_bounds__(FNT) void mlp_backward_fused_kernel(const gnc_mlp_d
     load_tile_rows(pe, s0.ptr, s0.ld, row0, rows, e_off);
     load_tile_rows(pg, b.grad_out, b.ld_grad_out, row0, rows, g_off);
     if constexpr (NADD > 0) {
-      int r = row0 + (lane & 31);
-      r = r < rows ? r : rows - 1;
+      const int ids_cur[2] = {ids_nxt[0], ids_nxt[1]};
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const gnc_mlp_segment_t& sg = d.seg[1 + k];
         const __amdgpu_buffer_rsrc_t w =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.ptr), 0, (int)(uint32_t)(sg.table_rows * sg.ld * 4), 0x00020000);
-        const int rb = sg.index[r] * (sg.ld * 4);
+        const int rb = ids_cur[k] * (sg.ld * 4);
         const uint32_t col = (uint32_t)(c4 * 4 < sg.ld ? c4 * 16 : 0);
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
@@ -461,6 +471,7 @@ __global__ __launch_bounds__(FNT) void mlp_backward_fused_kernel(const gnc_mlp_d
           if (k == 0) pa[p] = v; else pb[p] = v;
         }
       }
+      load_ids(wt + total_waves);
     }
     // ---------------------------------------------------------------- forward recompute
     to_tile(te, pe, s0.width);
@@ -527,6 +538,7 @@ __global__ __launch_bounds__(FNT) void mlp_backward_fused_kernel(const gnc_mlp_d
     // ---------------------------------------------------------------- layer 0: dW0 += dz0^T e, dz0 out, dx
     acc_to_tile(tb, g);
     xty_tile(dW0, cs0, tb, te, i, h);
+    asm volatile("" ::"v"(ids_nxt[0]), "v"(ids_nxt[1]));  // collected before the asm stores join the queue
     if (b.dz[0]) store_staged_rows(tb, b.dz[0], d.out_dim[0], d.out_dim[0], row0, rows, c4, rs);
     if (b.dx) {
       f32x16 dxs[HT];
