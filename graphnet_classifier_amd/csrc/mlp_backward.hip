@@ -76,6 +76,16 @@ __device__ __forceinline__ void apply_mask(f32x16 (&acc)[T], unsigned m) {
     for (int r = 0; r < 16; ++r) acc[t][r] = (m >> (16 * t + r)) & 1u ? acc[t][r] : 0.f;
 }
 
+// acc = acc where the (post-ReLU) activation is positive, else 0: the ReLU derivative taken from the activation
+// itself when that is still in registers (2 VALU per value, no bit masks to pack and unpack)
+template <int T>
+__device__ __forceinline__ void mask_by_positive(f32x16 (&acc)[T], const f32x16 (&act)[T]) {
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = act[t][r] > 0.f ? acc[t][r] : 0.f;
+}
+
 template <int T>
 __device__ __forceinline__ void tile_from_lds(f32x16 (&acc)[T], const float* abuf, int i, int h) {
 #pragma unroll
@@ -484,11 +494,11 @@ __global__ __launch_bounds__(FNT) void mlp_backward_fused_kernel(const gnc_mlp_d
       to_tile(ta, pa, d.seg[1].width);
       add_tile_from_lds<HT>(a0, ta, i, h);
     }
-    const unsigned m0 = relu_tiles_mask<HT>(a0);
+    relu_tiles<HT>(a0);
     f32x16 a1[HT];
     init_bias<HT>(a1, pbuf + PSTRIDE, h);
     mma_chunk_from_regs<HT, HT>(a1, a0, wres + CH, 0, d.in_dim[1], i, h);
-    const unsigned m1 = relu_tiles_mask<HT>(a1);
+    relu_tiles<HT>(a1);
     // ---------------------------------------------------------------- grad of the pre-LayerNorm output
     f32x16 g[HT];
     to_tile(tb, pg, out_dim);
@@ -519,7 +529,7 @@ __global__ __launch_bounds__(FNT) void mlp_backward_fused_kernel(const gnc_mlp_d
       f32x16 da[HT];
       zero_tiles<HT>(da);
       mma_transposed_from_regs<HT, HT>(da, g, wres + 2 * CH, i, h);
-      apply_mask<HT>(da, m1);
+      mask_by_positive<HT>(da, a1);
 #pragma unroll
       for (int t = 0; t < HT; ++t) g[t] = da[t];
     }
@@ -531,7 +541,7 @@ __global__ __launch_bounds__(FNT) void mlp_backward_fused_kernel(const gnc_mlp_d
       f32x16 da[HT];
       zero_tiles<HT>(da);
       mma_transposed_from_regs<HT, HT>(da, g, wres + CH, i, h);
-      apply_mask<HT>(da, m0);
+      mask_by_positive<HT>(da, a0);
 #pragma unroll
       for (int t = 0; t < HT; ++t) g[t] = da[t];
     }
