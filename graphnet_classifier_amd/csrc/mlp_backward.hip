@@ -29,9 +29,12 @@ constexpr int BNT = BWAVES * 64;
 
 // dst[t'] += W^T-tile * src: contraction over the feature index n of src (register r of tile t holds
 // n = 32t + (r&3) + 8(r>>2) + 4h); A operand = W[n][32t' + i] read down the column of the [n][k] chunk.
-template <int TI, int TO>
+// FROM_ZERO: dst = product (the first MFMA of every tile takes the constant 0 as its C operand, so no register set
+// has to be cleared first)
+template <int TI, int TO, bool FROM_ZERO = false>
 __device__ __forceinline__ void mma_transposed_from_regs(f32x16 (&dst)[TO], const f32x16 (&src)[TI], const float* wbuf,
                                                          int i, int h) {
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int t = 0; t < TI; ++t)
 #pragma unroll
@@ -40,7 +43,7 @@ __device__ __forceinline__ void mma_transposed_from_regs(f32x16 (&dst)[TO], cons
 #pragma unroll
       for (int tp = 0; tp < TO; ++tp) {
         const float a = wbuf[n * LDSW + 32 * tp + i];
-        dst[tp] = mfma(a, src[t][r], dst[tp]);
+        dst[tp] = mfma(a, src[t][r], (FROM_ZERO && t == 0 && r == 0) ? zero : dst[tp]);
       }
     }
 }
@@ -527,8 +530,7 @@ __global__ __launch_bounds__(FNT) void mlp_backward_fused_kernel(const gnc_mlp_d
     xty_tile(dW2, cs2, tb, ta, i, h);
     {
       f32x16 da[HT];
-      zero_tiles<HT>(da);
-      mma_transposed_from_regs<HT, HT>(da, g, wres + 2 * CH, i, h);
+      mma_transposed_from_regs<HT, HT, true>(da, g, wres + 2 * CH, i, h);
       mask_by_positive<HT>(da, a1);
 #pragma unroll
       for (int t = 0; t < HT; ++t) g[t] = da[t];
@@ -539,8 +541,7 @@ __global__ __launch_bounds__(FNT) void mlp_backward_fused_kernel(const gnc_mlp_d
     xty_tile(dW1, cs1, tb, ta, i, h);
     {
       f32x16 da[HT];
-      zero_tiles<HT>(da);
-      mma_transposed_from_regs<HT, HT>(da, g, wres + CH, i, h);
+      mma_transposed_from_regs<HT, HT, true>(da, g, wres + CH, i, h);
       mask_by_positive<HT>(da, a0);
 #pragma unroll
       for (int t = 0; t < HT; ++t) g[t] = da[t];
@@ -552,8 +553,7 @@ __global__ __launch_bounds__(FNT) void mlp_backward_fused_kernel(const gnc_mlp_d
     if (b.dz[0]) store_staged_rows(tb, b.dz[0], d.out_dim[0], d.out_dim[0], row0, rows, c4, rs);
     if (b.dx) {
       f32x16 dxs[HT];
-      zero_tiles<HT>(dxs);
-      mma_transposed_from_regs<HT, HT>(dxs, g, wres, i, h);
+      mma_transposed_from_regs<HT, HT, true>(dxs, g, wres, i, h);
       acc_to_tile(ta, dxs);
       store_staged_rows(ta, b.dx + s0.wcol, b.ld_dx, s0.width, row0, rows, c4, rs, b.dx_add_grad_out ? b.grad_out : nullptr,
                         b.ld_grad_out);
