@@ -5,6 +5,8 @@ Bars: index work (CSR build) and the scatter-sum are checked BIT-EXACT (the CSR 
 summed in the reference's edge order); the fp32-MFMA MLP is checked to 1e-5 absolute on O(1)
 values (north_star tolerance), typically ~1e-6.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -318,6 +320,8 @@ def test_fused_aggregation_epilogue_bit_equals_k1(native, n, e, hot, d):
     y0 = native.mlp_forward(segs, ws, bs, ln=ln, residual=ea, modes=modes)
     y, agg = native.mlp_forward(segs, ws, bs, ln=ln, residual=ea, modes=modes,
                                 aggregate=(torch.from_numpy(dst).to(DEV), rowptr, n))
+    if agg is None and (os.environ.get("GNC_MLP_NO_RESIDENT") or os.environ.get("GNC_MLP_NO_STREAM2")):
+        pytest.skip("the kernel that carries the epilogue at this width is switched off by an A/B variable")
     assert agg is not None, "the W-split edge shape at widths 64 and 128 must take the fused epilogue"
     assert torch.equal(y, y0)
     ref = native.scatter_sum_csr(y, rowptr, None, n)
@@ -356,6 +360,8 @@ def test_fused_aggregation_random_shapes(native, d):
         dst_t = torch.from_numpy(dst).to(DEV)
         y, agg = native.mlp_forward([(ps, torch.from_numpy(src).to(DEV)), (pd, dst_t), (ea, None)], ws, bs, ln=ln, residual=ea,
                                     modes=modes, aggregate=(dst_t, rowptr, n))
+        if agg is None and (os.environ.get("GNC_MLP_NO_RESIDENT") or os.environ.get("GNC_MLP_NO_STREAM2")):
+            pytest.skip("the kernel that carries the epilogue at this width is switched off by an A/B variable")
         assert agg is not None
         assert torch.equal(agg, native.scatter_sum_csr(y, rowptr, None, n)), (n, e, k)
 
