@@ -8,10 +8,11 @@
 // chunks, then every later Linear) is the same for every tile, so the stream never stops: the
 // last chunk of a tile prefetches chunk 0 of the next.
 //
-// The per-wave side is the resident kernel's pipeline (mlp_resident.hip): unconditional, clamped
-// row loads one step ahead in registers, gather ids one tile ahead, additive (W-split) segments
-// summed in registers, hidden activations in accumulators across layers, stores issued from inline
-// asm so hipcc's vmcnt waits stay counted.
+// The per-wave side is the resident kernel's pipeline (mlp_resident.hip): unconditional row loads one
+// step ahead in registers (buffer windows for row-ordered tables, weight chunks and stated gather tables;
+// clamped ids), gather ids one tile ahead, additive (W-split) segments summed in registers, hidden
+// activations in accumulators across layers, stores issued from inline asm so hipcc's vmcnt waits stay
+// counted.  The 128-wide instance can also carry the aggregation epilogue (template flag AGG).
 #include <stdlib.h>
 
 #include "mlp_device.h"

@@ -3,8 +3,8 @@
 // At 256 features the 32-row formulation needs 2 x 128 accumulator registers per wave (the current and
 // the next layer), which forces one wave per SIMD and still spills (47 % of the fp32 MFMA peak at config
 // c5).  With the 16x16x4 shape a wave owns 16 data rows: the same 256 features are 16 tiles x 4
-// registers = 64 registers, two layers fit in 128, and the kernel runs 8 waves per CU (2 per SIMD) without
-// spilling.  The formulation is the same as mlp_fused.hip, transposed: accumulator register r of tile t on
+// registers = 64 registers, two layers fit in 128, and the kernel runs 8 waves per CU (2 per SIMD); the 256-wide
+// instance still spills 68 registers (272 B of scratch), the 128-wide ones none.  The formulation is the same as mlp_fused.hip, transposed: accumulator register r of tile t on
 // lane (j = lane & 15, g = lane >> 4) holds feature 16t + 4g + r of data row j, which is exactly the B
 // operand (k = 4g + r within the 16-wide k block t) of the next Linear; the matching A operand is
 // W[n][16t + 4g .. +3], one ds_read_b128.  Weight chunks ([features][64 k], padded rows of 68 floats) are
