@@ -1,0 +1,176 @@
+"""Tables past the 4 GiB mark.  Below 2^32 bytes the kernels address a row-ordered table through ONE
+loop-invariant buffer window (32-bit byte offsets); above it they switch to a window per tile
+(`full_tile_window` -> `row_window`, csrc/mlp_device.h) and the scatter / gather kernels to 64-bit row
+offsets.  BASELINE configs c2 (8.4 M x 128 x 4 B = 4.3 GB edge latents) and c5 (5 M x 256 x 4 B = 5.12 GB)
+live on that second path, so every kernel that streams `[E, D]` rows is checked here on a table larger
+than 2^32 bytes:
+
+  * sampled rows at the start, around the 4 GiB offset and at the very end against the CPU oracle;
+  * EVERY row beyond the 4 GiB offset bit-for-bit against the same kernel run on the upper part of the
+    table handed over as its own (< 4 GiB) table - same per-row arithmetic, different addressing path.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import graphnet_oracle as O
+from tests._util import max_abs
+from tests.test_gpu_kernels import _mlp_sd
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+FOUR_GIB = 1 << 32
+
+
+@pytest.fixture(scope="module")
+def native():
+    from graphnet_classifier_amd import native as n
+    n.load_library()
+    return n
+
+
+def _rows_for(width, extra=200_003):
+    """rows such that rows * width * 4 B > 4 GiB, with a ragged tail (not a multiple of any tile height)."""
+    return FOUR_GIB // (4 * width) + extra
+
+
+def _sample_rows(rows, width, k=48):
+    edge = FOUR_GIB // (4 * width)  # first row that starts at or beyond the 4 GiB byte offset
+    idx = np.unique(np.concatenate([np.arange(0, k), np.arange(edge - k, edge + k), np.arange(rows - k, rows)]))
+    assert idx[-1] == rows - 1 and (idx >= edge).sum() >= k
+    return torch.from_numpy(idx), edge
+
+
+def _dev_params(sd):
+    lin = sorted((k for k in sd if sd[k].ndim == 2), key=lambda k: int(k.split(".")[2]))
+    ws = [sd[k].to(DEV) for k in lin]
+    bs = [sd[k.replace("weight", "bias")].to(DEV) for k in lin]
+    lnk = [k for k in sd if k.endswith("weight") and sd[k].ndim == 1]
+    ln = (sd[lnk[0]].to(DEV), sd[lnk[0].replace("weight", "bias")].to(DEV), 1e-5) if lnk else None
+    return ws, bs, ln
+
+
+@pytest.mark.parametrize("width", [64, 128, 256])  # weights-resident / 32-row streaming / 16-row streaming kernel
+def test_mlp_forward_row_table_beyond_4gib(native, width):
+    rng = np.random.default_rng(width)
+    rows = _rows_for(width)
+    assert rows * width * 4 > FOUR_GIB
+    sd = _mlp_sd(rng, width, width, width, 2, True)
+    ws, bs, ln = _dev_params(sd)
+    x = torch.randn(rows, width, device=DEV, generator=torch.Generator(device=DEV).manual_seed(width))
+    y = native.mlp_forward([(x, None)], ws, bs, ln=ln, residual=x)
+    assert y.shape == (rows, width)
+    idx, edge = _sample_rows(rows, width)
+    xs = x[idx.to(DEV)].cpu()
+    ref = O.mlp_forward(sd, "m", xs) + xs
+    assert max_abs(y[idx.to(DEV)].cpu(), ref) < 1e-5
+    # every row whose bytes lie beyond 4 GiB, against the < 4 GiB addressing path of the same kernel
+    lo = edge - 1000
+    y_hi = native.mlp_forward([(x[lo:], None)], ws, bs, ln=ln, residual=x[lo:])
+    assert torch.equal(y[lo:], y_hi)
+    # and nothing below was disturbed by the window switch: first rows again through a small table
+    y_lo = native.mlp_forward([(x[:5000], None)], ws, bs, ln=ln, residual=x[:5000])
+    assert torch.equal(y[:5000], y_lo)
+
+
+@pytest.mark.parametrize("width", [128, 256])
+def test_edge_processor_wsplit_and_aggregation_beyond_4gib(native, width):
+    """The W-split edge launch (two gathered ADD segments + the row-ordered e table, residual e, aggregation epilogue
+    where the kernel has one) with e and e' larger than 4 GiB, against K1 on the stored rows (bit-exact) and the
+    oracle on sampled edges."""
+    rng = np.random.default_rng(width + 1)
+    e = _rows_for(width, 77_777)
+    n = e // 8
+    sd = _mlp_sd(rng, 3 * width, width, width, 2, True)
+    ws, bs, ln = _dev_params(sd)
+    w0 = ws[0]
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(n, width, device=DEV, generator=gen)
+    ea = torch.randn(e, width, device=DEV, generator=gen)
+    dst = torch.sort(torch.randint(0, n, (e,), device=DEV, generator=gen, dtype=torch.int32)).values
+    src = torch.randint(0, n, (e,), device=DEV, generator=gen, dtype=torch.int32)
+    rowptr = torch.zeros(n + 1, dtype=torch.int32, device=DEV)
+    rowptr[1:] = torch.cumsum(torch.bincount(dst.long(), minlength=n), 0).int()
+    ps = native.mlp_forward([(x, None)], [w0[:, :width]], [None])
+    pd = native.mlp_forward([(x, None)], [w0[:, width:2 * width]], [None])
+    modes = [native.SEG_ADD, native.SEG_ADD, native.SEG_MATMUL]
+    y, agg = native.mlp_forward([(ps, src), (pd, dst), (ea, None)], [w0[:, 2 * width:]] + ws[1:], bs, ln=ln, residual=ea,
+                                modes=modes, aggregate=(dst, rowptr, n))
+    k1 = native.scatter_sum_csr(y, rowptr, None, n)
+    if agg is not None:
+        assert torch.equal(agg, k1)
+    idx, edge = _sample_rows(e, width)
+    di = idx.to(DEV)
+    cat = torch.cat([x[src[di].long()], x[dst[di].long()], ea[di]], -1).cpu()
+    ref = O.mlp_forward(sd, "m", cat) + ea[di].cpu()
+    assert max_abs(y[di].cpu(), ref) < 1e-5
+    # K1 itself beyond 4 GiB: the last destinations, summed on the host in edge order
+    last = torch.arange(n - 64, n)
+    a, b = int(rowptr[n - 64]), int(rowptr[n])
+    ref_agg = O.scatter_sum(y[a:b].cpu(), dst[a:b].long().cpu() - (n - 64), dim_size=64)
+    assert a * width * 4 > FOUR_GIB and torch.equal(k1[last.to(DEV)].cpu(), ref_agg)
+
+
+@pytest.mark.parametrize("d", [128, 256])
+def test_scatter_and_gathers_beyond_4gib(native, d):
+    """K1 (sorted and through a permutation), K2 and the gather-add with [E, D] operands larger than 4 GiB."""
+    e = _rows_for(d, 50_001)
+    n = e // 10
+    gen = torch.Generator(device=DEV).manual_seed(d)
+    msg = torch.randn(e, d, device=DEV, generator=gen)
+    index = torch.randint(0, n, (e,), device=DEV, generator=gen, dtype=torch.int64)
+    rowptr, perm, status = native.csr_build(index, n)
+    assert status.tolist() == [0, 0]
+    out_perm = native.scatter_sum_csr(msg, rowptr, perm, n)
+    sorted_msg = native.gather_rows(msg, perm)                      # K2 with table and output > 4 GiB
+    assert torch.equal(sorted_msg[-1000:], msg[perm[-1000:].long()])
+    assert torch.equal(sorted_msg[:1000], msg[perm[:1000].long()])
+    out_sorted = native.scatter_sum_csr(sorted_msg, rowptr, None, n)
+    assert torch.equal(out_perm, out_sorted)
+    # host check of destinations whose messages sit beyond the 4 GiB offset of the sorted table
+    first = int(torch.searchsorted(rowptr.long(), torch.tensor(FOUR_GIB // (4 * d) + 1, device=DEV)))
+    for v0 in (0, first, n - 32):
+        a, b = int(rowptr[v0]), int(rowptr[v0 + 32])
+        ref = O.scatter_sum(sorted_msg[a:b].cpu(), torch.repeat_interleave(torch.arange(32), (rowptr[v0 + 1:v0 + 33] - rowptr[v0:v0 + 32]).long().cpu()), dim_size=32)
+        assert torch.equal(out_sorted[v0:v0 + 32].cpu(), ref)
+    # gather-add: out[r] = table[index[r]] + addend[r], addend and out > 4 GiB
+    dst32 = index.int()
+    ga = native.gather_rows_add(out_sorted, dst32, msg)
+    for sl in (slice(0, 2000), slice(e - 2000, e)):
+        assert torch.equal(ga[sl], out_sorted[dst32[sl].long()] + msg[sl])
+
+
+@pytest.mark.parametrize("width", [64, 128, 256])
+def test_mlp_backward_row_tables_beyond_4gib(native, width):
+    """K8: grad_out, dx and the emitted tensors larger than 4 GiB; rows beyond the offset bit-for-bit against the
+    same kernel on the upper part of the tables, sampled rows against float64 autograd."""
+    rng = np.random.default_rng(width + 7)
+    rows = _rows_for(width, 33_333)
+    sd = _mlp_sd(rng, width, width, width, 2, True)
+    ws, bs, ln = _dev_params(sd)
+    gen = torch.Generator(device=DEV).manual_seed(width)
+    x = torch.randn(rows, width, device=DEV, generator=gen)
+    g = torch.randn(rows, width, device=DEV, generator=gen)
+    segs = [(x, None)]
+    if not native.mlp_backward_supported(segs, ws, bs, ln, "ReLU", None, rows):
+        pytest.skip(f"no K8 kernel at width {width}")
+    r = native.mlp_backward(segs, ws, bs, ln, g, rows=rows, need_dx=True, fused=False)
+    idx, edge = _sample_rows(rows, width, k=24)
+    di = idx.to(DEV)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    xs = x[di].cpu().double().requires_grad_(True)
+    h = xs
+    for i in (0, 2, 4):
+        h = torch.nn.functional.linear(h, sd64[f"m.model.{i}.weight"], sd64[f"m.model.{i}.bias"])
+        if i < 4:
+            h = torch.relu(h)
+    h = torch.nn.functional.layer_norm(h, (width,), sd64["m.model.5.weight"], sd64["m.model.5.bias"], 1e-5)
+    h.backward(g[di].cpu().double())
+    assert max_abs(r["dx"][di].cpu(), xs.grad.float()) < 5e-5
+    lo = edge - 512
+    r2 = native.mlp_backward([(x[lo:], None)], ws, bs, ln, g[lo:], rows=rows - lo, need_dx=True, fused=False)
+    assert torch.equal(r["dx"][lo:], r2["dx"])
+    for a, b in zip(r["dz"], r2["dz"]):
+        assert torch.equal(a[lo:], b)
+    for a, b in zip(r["act"], r2["act"]):
+        assert torch.equal(a[lo:], b)

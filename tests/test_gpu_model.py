@@ -214,10 +214,12 @@ def test_edge_order_invariance(G):
     assert max_abs(a, b) < 5e-6
 
 
-@pytest.mark.parametrize("name,scale", [("c3", 1.0), ("c2", 0.2), ("c5", 0.25)])
+@pytest.mark.parametrize("name,scale", [("c3", 1.0), ("c2", 1.0), ("c5", 1.0)])
 def test_full_size_workload_against_oracle_on_sampled_graphs(G, name, scale):
-    """BASELINE.json sizes: the whole batch runs on the GPU; graphs are independent (block
-    diagonal), so the oracle checks the first, middle and last graphs of the batch exactly."""
+    """BASELINE.json sizes, all at FULL size: the whole batch runs on the GPU; graphs are independent (block
+    diagonal), so the oracle checks the first, middle and last graphs of the batch exactly.  At c2 / c5 the
+    edge-latent tables are 4.3 GB / 5.12 GB, so the last graphs' edges lie beyond the 4 GiB offset where the
+    kernels switch from one whole-table buffer window to a window per tile (csrc/mlp_device.h)."""
     from graphnet_classifier_amd import synthetic as S
     batch, kw = S.make_workload(name, scale)
     torch.manual_seed(11)
@@ -227,6 +229,8 @@ def test_full_size_workload_against_oracle_on_sampled_graphs(G, name, scale):
     assert y.shape == (batch.num_nodes, 1) and bool(torch.isfinite(y).all())
     sd = {k: v.cpu() for k, v in m.state_dict().items()}
     ng = batch.num_graphs
+    if name != "c3":
+        assert batch.num_edges * kw["out_dim_edge"] * 4 > (1 << 32)
     for g0 in (0, ng // 2, ng - 3):
         s = batch.slice_graphs(g0, g0 + 3)
         ref = O.graphnet_forward(sd, s.x, s.pos, s.edge_index)
