@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Contract benchmark of the GraphNet forward hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c5] [--scaling weak|strong]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c5] [--scaling strong|weak]
 
 One "step" = one pass of the hot path over one synthetic batch that is already resident in
 HBM: destination-CSR build for the batch's edge_index (topology cache cleared, so it is paid
@@ -10,9 +10,15 @@ gather/concat/MLP/LayerNorm/residual kernel and the CSR scatter-sum, decoder).
 
 Default workload = BASELINE.json configs[2] "c3": 1M nodes / 10M edges, all widths 64, 2 GN
 blocks -- the configuration the metric's HBM-roofline target is quoted on.  For N > 1 the
-driver starts one process per GPU (torch.distributed.run); graphs are independent, so every
-rank runs the forward on its own batch with no data-path collective ("weak": every rank gets a
-full-size batch; "strong": the c3 graphs are split by graph id, config c4).
+driver starts one process per GPU (torch.distributed.run) and the default is BASELINE.json
+configs[3] "c4": the SAME c3 batch split by graph id into N contiguous ranges balanced by edges
+("strong": total work fixed; `--scaling weak` gives every rank its own full-size batch instead).
+Graphs are independent, so the timed forward has no data-path collective.
+
+After the timed region the same JSON line gets a `train` object: a few training steps (forward + CE
+loss + backward on the K8 kernels + ONE flat-gradient all-reduce over RCCL when N > 1 + fused Adam,
+reference utils/train_model.py:37-42 with the collective inserted at :41-42), with the all-reduce timed
+separately (`allreduce_ms`).  `--mode train` makes that step the timed metric instead.
 
 Prints ONE JSON line on rank 0.  value = edges aggregated per second over the whole job
 (= sum over ranks of E_rank * n_blocks * steps / max-over-ranks wall time).
@@ -59,7 +65,7 @@ def usable_cpus() -> int:
         except (OSError, ValueError, IndexError):
             continue
     env = os.environ.get("GNC_CPU_THREADS")
-    return int(env) if env else min(n, 16)  # 16 = the documented CPU share of a 1-GPU box
+    return int(env) if env else n  # the cgroup's CPU share (16 on a 1-GPU box of this pool)
 
 
 def cpu_baseline(batch, kw, n_blocks, target_seconds=12.0):
@@ -91,7 +97,7 @@ def cpu_baseline(batch, kw, n_blocks, target_seconds=12.0):
     return {"value": s.num_edges * n_blocks / t, "unit": "edges aggregated/s", "cores": torch.get_num_threads(),
             "kind": "port", "sample": f"first {ngraphs} of {batch.num_graphs} graphs of the same batch "
             f"({s.num_nodes} nodes, {s.num_edges} edges), one forward, {t:.2f} s",
-            "graphs_per_s": ngraphs / t}, (s, y)
+            "graphs_per_s": ngraphs / t}, (s, y), sd
 
 
 def main():
@@ -101,13 +107,17 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--preheat-ms", type=float, default=600.0, help="untimed device pre-heat before the warm-up steps")
     ap.add_argument("--workload", default="c3", choices=sorted(synthetic.WORKLOADS))
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
+                    help="strong (default): one workload split by graph id over the ranks (c3 over N GPUs = BASELINE config c4); "
+                         "weak: every rank its own full-size batch")
+    ap.add_argument("--train-steps", type=int, default=5,
+                    help="training steps of the extra `train` leg after the timed forward region (0 = skip it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scale", type=float, default=1.0,
                     help="fraction of the workload's graphs (tests / rehearsals only; the contract number is --scale 1)")
     ap.add_argument("--mode", default="forward", choices=["forward", "train"],
-                    help="train: forward + cross-entropy + backward (HIP K8 kernels) + one flat gradient all-reduce "
-                         "(RCCL, world > 1) + Adam, graphs batched block-diagonally (c3/c5 only: equal-size graphs)")
+                    help="train: the timed step is forward + cross-entropy + backward (HIP K8 kernels) + one flat gradient "
+                         "all-reduce (RCCL, world > 1) + fused Adam, graphs batched block-diagonally")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -145,29 +155,54 @@ def main():
     model.eval()
     x, pos, ei = batch.x.to(dev), batch.pos.to(dev), batch.edge_index.to(dev)
 
-    if a.mode == "train":
+    global_graphs = batch.num_graphs
+    if world > 1:
+        gg = torch.tensor([batch.num_graphs], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(gg)
+        global_graphs = int(gg.item())
+
+    def make_train_step():
+        """utils/train_model.py:37-42 on the block-diagonal batch of this rank: forward (read-out per graph), CE loss,
+        backward, ONE flat-gradient all-reduce (world > 1), fused Adam.  Ranks own unequal graph counts (the split
+        balances edges), so every rank scales its SUM-reduced loss by 1 / global graph count and the all-reduce is a
+        plain SUM: the result is exactly the gradient of the global-batch mean loss."""
         from graphnet_classifier_amd.GNN import CombinedModel
-        from graphnet_classifier_amd.sharding import FlatGradAllReduce
-        nodes_per_graph = batch.num_nodes // batch.num_graphs
-        if nodes_per_graph * batch.num_graphs != batch.num_nodes or a.workload == "c2":
-            sys.exit("--mode train needs equal-size graphs (workloads c3, c5)")
+        from graphnet_classifier_amd.train import FlatParameters, FusedAdam
+        sizes = (batch.graph_ptr[1:] - batch.graph_ptr[:-1])
+        equal = bool((sizes == sizes[0]).all())
+        num_nodes = int(sizes.max())
         torch.manual_seed(0)
-        cmodel = CombinedModel(GraphNet(**kw), num_nodes=nodes_per_graph, classes=2).to(dev)
+        cmodel = CombinedModel(GraphNet(**kw), num_nodes=num_nodes, classes=2).to(dev)
         cmodel.train()
         labels = torch.randint(0, 2, (batch.num_graphs,), generator=torch.Generator().manual_seed(rank)).to(dev)
-        opt = torch.optim.Adam(cmodel.parameters(), lr=1e-3)   # utils/train_model.py:9
-        crit = torch.nn.CrossEntropyLoss()                     # utils/train_model.py:10
-        reducer = FlatGradAllReduce(cmodel.parameters())
+        flat = FlatParameters(cmodel, average=False)
+        opt = FusedAdam(flat, lr=1e-3)                            # utils/train_model.py:9
+        crit = torch.nn.CrossEntropyLoss(reduction="sum")         # :10, mean taken over the GLOBAL batch below
+        gptr = None if equal else batch.graph_ptr.to(dev)
+        ar = {"events": []}
 
-        def step():
+        def tstep():
             clear_topology_cache()
-            logits = cmodel.forward_batched(x, pos, ei, batch.num_graphs)
-            loss = crit(logits, labels)
+            if equal:
+                logits = cmodel.forward_batched(x, pos, ei, batch.num_graphs)
+            else:
+                logits = cmodel.forward_batched(x, pos, ei, graph_ptr=gptr)
+            loss = crit(logits, labels) / global_graphs
             opt.zero_grad()
             loss.backward()
-            reducer()  # ONE all-reduce of the flat gradient buffer (no-op at world size 1)
-            opt.step()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            flat.reducer()          # gradient pack + ONE all-reduce of the flat buffer (RCCL; nothing to reduce at world 1)
+            e1.record()
+            ar["events"].append((e0, e1))
+            opt.step(reduce=False)  # one fused Adam launch over the flat buffers
             return logits
+        return tstep, flat, ar
+
+    train_ctx = None
+    if a.mode == "train":
+        step, flat_params, ar_events = make_train_step()
+        train_ctx = (flat_params, ar_events)
     else:
         def step():
             clear_topology_cache()  # the CSR build belongs to the step
@@ -218,6 +253,7 @@ def main():
         marks[k + 1].record()
     fence()
     elapsed = time.perf_counter() - t0
+    y_fwd = y
     device_allocs_timed = torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - allocs0
     per_step_order = [marks[k].elapsed_time(marks[k + 1]) for k in range(a.steps)]
     per_step = sorted(per_step_order)
@@ -257,16 +293,46 @@ def main():
     native.set_kernel_timers(None)
     ksum = timers.summary()
 
-    stats = torch.tensor([elapsed, float(batch.num_edges), float(batch.num_graphs), float(batch.num_nodes)],
+    # ---- training leg (not part of `value` unless --mode train): BASELINE config c4's "RCCL grad all-reduce" lives here
+    t_train, ar_ms, train_steps, collectives = 0.0, 0.0, 0, 0
+    if a.mode == "train":
+        flat_params, ar_events = train_ctx
+        evs = ar_events["events"][-a.steps:]
+        torch.cuda.synchronize()
+        t_train, train_steps = elapsed, a.steps
+        ar_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / max(1, len(evs))
+        collectives = flat_params.reducer.collectives
+    elif a.train_steps > 0:
+        tstep, flat_params, ar_events = make_train_step()
+        for _ in range(2):
+            tstep()
+        fence()
+        ar_events["events"].clear()
+        c0 = flat_params.reducer.collectives
+        tt0 = time.perf_counter()
+        for _ in range(a.train_steps):
+            tstep()
+        fence()
+        t_train, train_steps = time.perf_counter() - tt0, a.train_steps
+        ar_ms = sum(e0.elapsed_time(e1) for e0, e1 in ar_events["events"]) / train_steps
+        collectives = flat_params.reducer.collectives - c0
+
+    stats = torch.tensor([elapsed, t_train, ar_ms, float(batch.num_edges), float(batch.num_graphs), float(batch.num_nodes)],
                          dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
-        tmax = stats[:1].clone()
+        tmax = stats[:3].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(stats[1:], op=dist.ReduceOp.SUM)
-        stats[0] = tmax[0]
-    elapsed, tot_edges, tot_graphs, tot_nodes = (float(v) for v in stats.cpu())
+        dist.all_reduce(stats[3:], op=dist.ReduceOp.SUM)
+        stats[:3] = tmax
+    elapsed, t_train, ar_ms, tot_edges, tot_graphs, tot_nodes = (float(v) for v in stats.cpu())
 
     if rank == 0:
+        if world > 1 and a.scaling == "strong":
+            wl_name = (f"{'c4' if a.workload == 'c3' else a.workload + '/' + str(world)}: {w['desc']}, split by graph id into {world} "
+                       f"contiguous ranges balanced by edges, one rank per GPU" + (" + RCCL all-reduce of the flat gradient buffer"
+                                                                                    if a.mode == "train" else ""))
+        else:
+            wl_name = f"{a.workload}: {w['desc']}" + (f", one such batch per rank x {world}" if world > 1 else "")
         k1 = ksum.get("scatter_sum_csr_sorted") or ksum.get("scatter_sum_csr_perm")
         k1_gbps = k1["avg_work"] / (k1["avg_ms"] * 1e-3) / 1e9
         traffic = None
@@ -284,7 +350,7 @@ def main():
             "unit": "edges/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": a.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{a.workload}: {w['desc']}" + ("" if a.scale == 1.0 else f" [scaled to {a.scale} of the graphs]"), "graphs": int(tot_graphs), "nodes": int(tot_nodes),
+            "config": {"workload": wl_name + ("" if a.scale == 1.0 else f" [scaled to {a.scale} of the graphs]"), "graphs": int(tot_graphs), "nodes": int(tot_nodes),
                        "edges": int(tot_edges), "n_blocks": n_blocks, "width": w["width"],
                        "step": "CSR build + GraphNet.forward, inputs resident in HBM" if a.mode == "forward" else
                                "CSR build + forward + CE loss + backward + flat grad all-reduce + Adam, inputs resident in HBM"},
@@ -295,6 +361,8 @@ def main():
                          if k1_isolated else "every K1 launch of the timed region",
                          "bound": "hbm", "achieved": k1_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": k1_gbps / HBM_PEAK_GBPS, "traffic": traffic,
+                         "traffic_source": "PMC counters of an earlier run of this kernel at this size, kept under profiles/ "
+                                           "(not measured in this run)" if traffic is not None else None,
                          "avg_launch_ms": k1["avg_ms"], "launches": k1["launches"],
                          "algorithmic_bytes_per_launch": k1["avg_work"]},
             "roofline_mlp": {"kernel": f"mlp_fused_kernel ({mlp_name}: fused gather+concat+MLP+LayerNorm+residual)",
@@ -310,13 +378,35 @@ def main():
             "kernel_ms_per_step": {k: v["avg_ms"] * v["launches"] / a.steps for k, v in ksum.items()
                                    if not (k1_isolated and k.startswith("scatter_sum_csr"))},
         }
+        if train_steps:
+            result["train"] = {
+                "step": "CSR build + forward + CE loss + backward + gradient pack + ONE flat all-reduce (world > 1) + fused Adam",
+                "steps": train_steps, "ms_per_step": t_train / train_steps * 1e3,
+                "value": tot_edges * n_blocks * train_steps / t_train, "unit": "edges/s",
+                "graphs_per_sec": tot_graphs * train_steps / t_train,
+                "allreduce_ms": ar_ms if world > 1 else 0.0, "gradient_pack_ms": ar_ms if world == 1 else None,
+                "allreduce_bytes": flat_params.grad.numel() * 4, "collectives_per_step": collectives / train_steps,
+                "backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None}
         if cached_ms is not None:
             result["topology_cached"] = {"ms_per_step": cached_ms, "value": tot_edges * n_blocks / (cached_ms * 1e-3),
                                          "note": "same step without the CSR build (rank 0's clock)"}
         if world == 1 and not a.no_cpu_baseline and a.mode == "forward":
-            base, (s, yref) = cpu_baseline(batch, kw, n_blocks)
+            base, (s, yref), sd = cpu_baseline(batch, kw, n_blocks)
             result["cpu_baseline"] = base
-            result["parity_max_abs_vs_oracle"] = float((y[: s.num_nodes].cpu() - yref).abs().max())
+            # parity in the same run: the timed sample (a prefix of the batch) AND the first / middle / last graphs, so that
+            # rows at the far end of the edge tables (beyond 4 GiB at c2 / c5) are looked at too
+            from oracle import graphnet_oracle as O
+            y_host = y_fwd.cpu()
+            err = float((y_host[: s.num_nodes] - yref).abs().max())
+            ng = batch.num_graphs
+            for g0 in sorted({0, max(0, ng // 2 - 1), max(0, ng - 3)}):
+                sg = batch.slice_graphs(g0, min(ng, g0 + 3))
+                with torch.no_grad():
+                    ref = O.graphnet_forward(sd, sg.x, sg.pos, sg.edge_index)
+                n0 = int(batch.graph_ptr[g0])
+                err = max(err, float((y_host[n0:n0 + sg.num_nodes] - ref).abs().max()))
+            result["parity_max_abs_vs_oracle"] = err
+            result["parity_checked"] = "timed CPU sample (prefix) + first / middle / last 3 graphs of the batch"
             result["speedup_vs_cpu_baseline"] = result["value"] / base["value"]
         print(json.dumps(result), flush=True)
     if world > 1:

@@ -20,7 +20,7 @@ from torch import Tensor
 from . import functional as Fn
 from . import native
 from .MLP import MLP, default_device, require_gpu_param
-from .topology import GraphTopology, get_topology
+from .topology import GraphTopology, get_destination_csr, get_topology
 
 
 # Algebraic split of the edge processor's first Linear (DESIGN.md, K4 "W-split"); GNC_NO_WSPLIT=1
@@ -48,9 +48,9 @@ def scatter_sum(src: Tensor, index: Tensor, dim: int = 0, dim_size: int | None =
     if dev.type != "cuda":
         raise RuntimeError("scatter_sum: no GPU visible and no CPU fallback exists")
     out_device = src.device
-    ei = torch.stack([index.long(), index.long()])  # only the destination row is used
-    topo = get_topology(ei, dim_size, dev)
-    out = Fn.scatter_sum_csr(src.to(device=dev, dtype=torch.float32), topo.rowptr, topo.perm, topo.col32, dim_size)
+    csr = get_destination_csr(index, dim_size, dev)  # destination sort of `index` only; cached on the tensor itself
+    src = src.to(device=dev, dtype=torch.float32)
+    out = Fn.scatter_sum_csr(src, csr.rowptr, csr.perm, csr.col32 if src.requires_grad else None, dim_size)
     return out if out_device == dev else out.to(out_device)
 
 

@@ -88,7 +88,7 @@ int sort_temp_bytes(int64_t num_edges, unsigned bits, size_t* bytes) {
 
 int grid_for(int64_t n) {
   int64_t g = gnc::ceil_div(n > 0 ? n : 1, gnc::kBlock);
-  const int64_t cap = gnc::kNumCU * 8;
+  const int64_t cap = gnc::num_cu() * 8;
   return (int)(g < cap ? g : cap);
 }
 

@@ -21,7 +21,9 @@ inline int check_hip(hipError_t e, const char* what) {
 inline int check_launch(const char* kernel) { return check_hip(hipGetLastError(), kernel); }
 
 constexpr int kWave = 64;        // gfx950 wavefront
-constexpr int kNumCU = 256;      // MI355X
+constexpr int kNumCUMax = 256;   // MI355X in SPX mode; a partitioned device (CPX/DPX) shows fewer
+// Compute units of the CURRENT device, queried once per device (persistent grids are sized from it).
+int num_cu();
 constexpr int kBlock = 256;      // default workgroup: 4 waves, one per SIMD
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

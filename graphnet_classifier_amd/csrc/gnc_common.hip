@@ -13,6 +13,18 @@ void set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+
+int num_cu() {
+  static int cached[64] = {0};  // 0 = not asked yet; benign race: every thread stores the same value
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return kNumCUMax;
+  if (cached[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = kNumCUMax;
+    cached[dev] = n > kNumCUMax ? kNumCUMax : n;
+  }
+  return cached[dev];
+}
 }  // namespace gnc
 
 extern "C" {

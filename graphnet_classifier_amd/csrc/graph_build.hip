@@ -25,7 +25,7 @@ inline size_t align_up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
 
 int grid_for(int64_t n) {
   int64_t g = gnc::ceil_div(n > 0 ? n : 1, gnc::kBlock);
-  const int64_t cap = gnc::kNumCU * 8;
+  const int64_t cap = gnc::num_cu() * 8;
   return (int)(g < cap ? g : cap);
 }
 

@@ -1192,14 +1192,14 @@ int launch_bwd_stream(const gnc_mlp_desc_t& d, const BwdArgs& b, const BwdPlan& 
     attr_set = true;
   }
   const int64_t num_tiles = gnc::ceil_div(d.rows, (int64_t)4 * RPW);
-  const int64_t grid = num_tiles < gnc::kNumCU ? num_tiles : gnc::kNumCU;
+  const int64_t grid = num_tiles < gnc::num_cu() ? num_tiles : gnc::num_cu();
   mlp_backward_stream_kernel<HT><<<dim3((unsigned)grid), dim3(256), smem, stream>>>(d, b, pl, (int)num_tiles);
   return gnc::check_launch("mlp_backward_stream_kernel");
 }
 
 int bwd_grid(int64_t rows) {
   int64_t grid = gnc::ceil_div(gnc::ceil_div(rows, RPW), BWAVES);
-  return (int)(grid > gnc::kNumCU ? gnc::kNumCU : grid);
+  return (int)(grid > gnc::num_cu() ? gnc::num_cu() : grid);
 }
 
 }  // namespace
@@ -1241,7 +1241,7 @@ int fused_shape(const gnc_mlp_desc_t& d) {
 }
 int fused_grid(int64_t rows) {
   const int64_t grid = gnc::ceil_div(gnc::ceil_div(rows, RPW), FWAVES);
-  return (int)(grid > gnc::kNumCU ? gnc::kNumCU : grid);
+  return (int)(grid > gnc::num_cu() ? gnc::num_cu() : grid);
 }
 constexpr size_t kFusedSmem = ((size_t)3 * 2 * 32 * LDSW + (size_t)5 * 64 + (size_t)FWAVES * 3 * RPW * LDSW) * sizeof(float);
 
@@ -1362,7 +1362,7 @@ extern "C" int gnc_mlp_backward_ln_partial_rows(const gnc_mlp_desc_t* fwd) {
 
 extern "C" int gnc_xty_partials(int64_t rows) {
   int64_t tiles = gnc::ceil_div(rows > 0 ? rows : 1, RPW);
-  int64_t waves = tiles < 4 * gnc::kNumCU * 2 ? tiles : 4 * gnc::kNumCU * 2;  // <= 2 blocks of 4 waves per CU
+  int64_t waves = tiles < 4 * gnc::num_cu() * 2 ? tiles : 4 * gnc::num_cu() * 2;  // <= 2 blocks of 4 waves per CU
   waves = (waves + 3) / 4 * 4;
   return (int)waves;
 }

@@ -45,7 +45,9 @@ __device__ __forceinline__ void stage_rows(float* abuf, const gnc_mlp_segment_t&
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (r < rows) {
         const int64_t tr = seg.index ? (int64_t)seg.index[r] : r;
-        v = load4_guarded(seg.ptr + tr * seg.ld + c0 + c4 * 4, c0 + c4 * 4, seg.width, vec_ok);
+        // an id outside the stated table reads zeros, as in the window-addressed kernels (never a fault)
+        if (!seg.index || (uint64_t)tr < (uint64_t)seg.table_rows)
+          v = load4_guarded(seg.ptr + tr * seg.ld + c0 + c4 * 4, c0 + c4 * 4, seg.width, vec_ok);
       }
       *reinterpret_cast<f32x4*>(abuf + j * LDSW + c4 * 4) = v;
     }
@@ -174,7 +176,7 @@ int launch(const gnc_mlp_desc_t& d, hipStream_t stream) {
   }
   const int64_t num_tiles = gnc::ceil_div(d.rows, RPB);
   const int per_cu = (int)((160 * 1024) / smem) < 1 ? 1 : (int)((160 * 1024) / smem);
-  int64_t grid = (int64_t)gnc::kNumCU * (per_cu > 3 ? 3 : per_cu);
+  int64_t grid = (int64_t)gnc::num_cu() * (per_cu > 3 ? 3 : per_cu);
   if (grid > num_tiles) grid = num_tiles;
   mlp_fused_kernel<HT, OT><<<dim3((unsigned)grid), dim3(NT), smem, stream>>>(d, num_tiles);
   return gnc::check_launch("mlp_fused_kernel");
@@ -200,8 +202,8 @@ int gnc_mlp::validate_desc(const gnc_mlp_desc_t* d, bool check_ptrs) {
       return GNC_ERR_INVALID_ARGUMENT;
     }
     if (check_ptrs && d->rows > 0 && !d->seg[s].ptr) { gnc::set_error("gnc_mlp: segment %d null", s); return GNC_ERR_INVALID_ARGUMENT; }
-    if (d->seg[s].index && d->seg[s].table_rows < 0) {
-      gnc::set_error("gnc_mlp: segment %d states a table of %lld rows", s, (long long)d->seg[s].table_rows);
+    if (d->seg[s].index && (d->seg[s].table_rows < 0 || (d->seg[s].table_rows == 0 && d->rows > 0))) {
+      gnc::set_error("gnc_mlp: gathered segment %d must state its table (table_rows = %lld)", s, (long long)d->seg[s].table_rows);
       return GNC_ERR_INVALID_ARGUMENT;
     }
     if (d->seg[s].mode == GNC_SEG_ADD) {

@@ -450,8 +450,8 @@ int launch(const gnc_mlp_desc_t& d, int total_chunks, size_t smem, hipStream_t s
   }
   const int64_t num_wtiles = gnc::ceil_div(d.rows, RPW);
   int64_t grid = gnc::ceil_div(num_wtiles, RWAVES);
-  if (grid > gnc::kNumCU) grid = gnc::kNumCU;  // one persistent workgroup per CU
-  if constexpr (AGG) grid = gnc::kNumCU;        // agg_fix has two entries for every wave of the full grid
+  if (grid > gnc::num_cu()) grid = gnc::num_cu();  // one persistent workgroup per CU
+  if constexpr (AGG) grid = gnc::num_cu();        // agg_fix has two entries for every wave of the full grid
   mlp_resident_kernel<HT, OT, NMM, NADD, RESREG, AGG>
       <<<dim3((unsigned)grid), dim3(RNT), smem, stream>>>(d, (int)num_wtiles, total_chunks);
   return gnc::check_launch("mlp_resident_kernel");
@@ -461,7 +461,7 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace
 
-extern "C" int gnc_mlp_agg_fix_len(void) { return 2 * gnc::kNumCU * RWAVES; }
+extern "C" int gnc_mlp_agg_fix_len(void) { return 2 * gnc::num_cu() * RWAVES; }
 
 int gnc_mlp::launch_resident(const gnc_mlp_desc_t& d, int T, bool narrow_out, hipStream_t stream, bool* launched,
                              bool probe_only) {

@@ -156,9 +156,11 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_stream_kernel(const gnc_mlp_de
         for (int p = 0; p < NP; ++p) pre[p] = window_load(w, (uint32_t)__shfl(row_bytes, p * 4 + rs, 64) + (uint32_t)(col * 4));
       } else {
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
+        for (int p = 0; p < NP; ++p) {  // table of 4 GiB or more: flat addresses, the id checked by hand (outside -> zeros)
           const int tr = __shfl(idxv, p * 4 + rs, 64);
-          pre[p] = *reinterpret_cast<const f32x4*>(base + (int64_t)tr * ld + col);
+          const bool ok = (uint64_t)(int64_t)tr < (uint64_t)d.seg[s].table_rows;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(base + (int64_t)(ok ? tr : 0) * ld + col);
+          pre[p] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
         }
       }
     }
@@ -453,8 +455,8 @@ int launch(const gnc_mlp_desc_t& d, const StreamPlan& pl, hipStream_t stream) {
     attr_set = true;
   }
   const int64_t num_tiles = gnc::ceil_div(d.rows, (int64_t)WAVES * RPW);
-  int64_t grid = num_tiles < gnc::kNumCU ? num_tiles : gnc::kNumCU;  // one persistent workgroup per CU
-  if constexpr (AGG) grid = gnc::kNumCU;  // agg_fix has two entries for every wave of the full grid (8 waves per workgroup)
+  int64_t grid = num_tiles < gnc::num_cu() ? num_tiles : gnc::num_cu();  // one persistent workgroup per CU
+  if constexpr (AGG) grid = gnc::num_cu();  // agg_fix has two entries for every wave of the full grid (8 waves per workgroup)
   mlp_stream_kernel<HT, OT, WAVES, DBUF, ADD2, AGG><<<dim3((unsigned)grid), dim3(WAVES * 64), smem, stream>>>(d, pl, (int)num_tiles);
   return gnc::check_launch("mlp_stream_kernel");
 }

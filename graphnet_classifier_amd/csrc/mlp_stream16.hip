@@ -239,9 +239,11 @@ __global__ __launch_bounds__(NT16) void mlp_stream16_kernel(const gnc_mlp_desc_t
         for (int p = 0; p < NP16; ++p) pre[p] = window_load(w, (uint32_t)__shfl(row_bytes, p * 4 + rs, 64) + (uint32_t)(col * 4));
       } else {
 #pragma unroll
-        for (int p = 0; p < NP16; ++p) {
+        for (int p = 0; p < NP16; ++p) {  // table of 4 GiB or more: flat addresses, the id checked by hand (outside -> zeros)
           const int tr = __shfl(idxv, p * 4 + rs, 64);
-          pre[p] = *reinterpret_cast<const f32x4*>(base + (int64_t)tr * ld + col);
+          const bool ok = (uint64_t)(int64_t)tr < (uint64_t)d.seg[s].table_rows;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(base + (int64_t)(ok ? tr : 0) * ld + col);
+          pre[p] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
         }
       }
     }
@@ -422,7 +424,7 @@ int launch16(const gnc_mlp_desc_t& d, const Plan16& pl, hipStream_t stream) {
     attr_set = true;
   }
   const int64_t num_tiles = gnc::ceil_div(d.rows, (int64_t)W16 * R16);
-  const int64_t grid = num_tiles < gnc::kNumCU ? num_tiles : gnc::kNumCU;
+  const int64_t grid = num_tiles < gnc::num_cu() ? num_tiles : gnc::num_cu();
   mlp_stream16_kernel<NTH, NTO, DBUF><<<dim3((unsigned)grid), dim3(NT16), smem, stream>>>(d, pl, (int)num_tiles);
   return gnc::check_launch("mlp_stream16_kernel");
 }

@@ -236,7 +236,7 @@ int launch_scatter(const float* src, int64_t ld_src, const int32_t* rowptr, cons
   const int waves_per_block = gnc::kBlock / kWave;
   if (vec4_ok(src, ld_src, d) && vec4_ok(out, ld_out, d)) {
     int64_t blocks = gnc::ceil_div(chunks, waves_per_block);
-    const int64_t cap = gnc::kNumCU * 16;
+    const int64_t cap = gnc::num_cu() * 16;
     if (blocks > cap) blocks = cap;
     dim3 grid((unsigned)blocks), block(gnc::kBlock);
     switch (pow2_lanes_for(d)) {
@@ -253,7 +253,7 @@ int launch_scatter(const float* src, int64_t ld_src, const int32_t* rowptr, cons
     return gnc::check_launch("scatter_sum_csr_vec4");
   }
   int64_t blocks = gnc::ceil_div(n, waves_per_block);
-  const int64_t cap = gnc::kNumCU * 16;
+  const int64_t cap = gnc::num_cu() * 16;
   if (blocks > cap) blocks = cap;
   scatter_sum_csr_scalar<HAS_PERM><<<dim3((unsigned)blocks), dim3(gnc::kBlock), 0, stream>>>(src, ld_src, rowptr, perm,
                                                                                               n, d, out, ld_out);
@@ -299,7 +299,7 @@ namespace {
 template <bool ADD>
 int launch_gather(const float* table, int64_t ld_table, const int32_t* index, const float* addend, int64_t ld_add,
                   int64_t num_rows, int32_t feat_dim, float* out, int64_t ld_out, hipStream_t stream) {
-  const int64_t cap = gnc::kNumCU * 16;
+  const int64_t cap = gnc::num_cu() * 16;
   if (vec4_ok(table, ld_table, feat_dim) && vec4_ok(out, ld_out, feat_dim) && (!ADD || vec4_ok(addend, ld_add, feat_dim))) {
     const int lpr = pow2_lanes_for(feat_dim);
     int64_t blocks = gnc::ceil_div(num_rows, 2 * (gnc::kBlock / lpr));
@@ -354,7 +354,7 @@ extern "C" int gnc_edge_features_f32(const float* pos, int32_t space_dim, const 
   if (num_edges == 0) return GNC_OK;
   GNC_REQUIRE(pos && src && dst && out, "gnc_edge_features_f32: null pointer");
   int64_t blocks = gnc::ceil_div(num_edges, gnc::kBlock);
-  const int64_t cap = gnc::kNumCU * 16;
+  const int64_t cap = gnc::num_cu() * 16;
   if (blocks > cap) blocks = cap;
   edge_features_kernel<<<dim3((unsigned)blocks), dim3(gnc::kBlock), 0, (hipStream_t)stream_>>>(pos, space_dim, src, dst,
                                                                                                num_edges, out, ld_out);

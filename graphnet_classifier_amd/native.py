@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 GNC_MAX_SEGMENTS = 4
 GNC_MAX_LINEAR = 8
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 ACTIVATIONS = {  # nn.<Name> accepted by the reference's MLP(activation=...) (models/MLP.py:21)
     "ReLU": 0, "Identity": 1, "Tanh": 2, "Sigmoid": 3, "SiLU": 4, "GELU": 5, "LeakyReLU": 6, "ELU": 7,
@@ -62,6 +62,8 @@ _SIGNATURES = {
     "gnc_rag_build": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
                                 c_void_p, c_size_t, c_void_p]),
     "gnc_colsum_pair_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_int32, c_void_p]),
+    "gnc_adam_step_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float,
+                                    c_void_p, c_void_p, c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -366,30 +368,21 @@ def make_mlp_desc(segments, weights, biases, ln, activation: str, act_param: flo
 
 SEG_MATMUL, SEG_ADD = 0, 1
 
-_padded_cache: dict = {}
-
-
-def _vector_rows(t: torch.Tensor, cache: bool = False) -> torch.Tensor:
+def _vector_rows(t: torch.Tensor) -> torch.Tensor:
     """Rows the kernels can read with 16-B vector loads: row stride a multiple of 4 floats and a 16-B
     aligned base.  Anything else (the reference's 3-column inputs and [H, 3] first-layer weights) is
-    copied once into a zero-padded buffer and handed over as a column slice of it; small weights are
-    cached by identity and version (an optimizer step bumps the version)."""
+    copied into a zero-padded buffer (one pad launch) and handed over as a column slice of it.  Nothing is
+    cached: the copy is made from the live tensor on every call, so in-place edits through ``.data``
+    (which do not bump ``_version``), ``load_state_dict`` and optimizer steps are always seen, and a
+    hipGraph capture records the pad itself instead of a pointer to a stale copy."""
     if t.data_ptr() % 16 == 0 and _ld(t) % 4 == 0:
         return t
-    key = (t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride())) if cache else None
-    if key is not None and key in _padded_cache:
-        return _padded_cache[key][0]
     cols = (t.size(1) + 3) // 4 * 4
-    buf = torch.zeros(t.size(0), cols, dtype=t.dtype, device=t.device)
-    buf[:, :t.size(1)] = t
-    view = buf[:, :t.size(1)]
-    if key is not None:
-        if len(_padded_cache) > 256:
-            _padded_cache.clear()
-        _padded_cache[key] = (view, t)  # keeps `t` alive so its address cannot be recycled under the key
-    return view
-
-
+    if t.stride(1) != 1 or t.stride(0) != t.size(1):
+        t = t.contiguous()
+    if cols == t.size(1):  # only the base address was off (a column slice of a wider tensor): fresh, aligned copy
+        return t.clone(memory_format=torch.contiguous_format)
+    return torch.nn.functional.pad(t, (0, cols - t.size(1)))[:, :t.size(1)]
 
 
 def _prepare_mlp(segments, weights, biases, residual, rows, modes):
@@ -414,7 +407,7 @@ def _prepare_mlp(segments, weights, biases, residual, rows, modes):
     if rows is None:
         t0, i0 = segments[0]
         rows = i0.numel() if i0 is not None else t0.size(0)
-    weights = [_vector_rows(_rowmajor(w.detach()), cache=True) for w in weights]
+    weights = [_vector_rows(_rowmajor(w.detach())) for w in weights]
     biases = [b.contiguous() if b is not None else None for b in biases]
     if residual is not None:
         residual = _rowmajor(residual)
@@ -600,3 +593,22 @@ def colsum_pair(g: torch.Tensor, y: torch.Tensor):
                                        _stream(g)), "gnc_colsum_pair_f32")
     tot = part.sum(dim=0)
     return tot[:width], tot[width:]
+
+
+# --------------------------------------------------------------------------- fused Adam
+def adam_step(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, step: torch.Tensor,
+              scratch: torch.Tensor, lr: float, beta1: float, beta2: float, eps: float, weight_decay: float = 0.0) -> None:
+    """One Adam update of the flat fp32 buffer ``param`` from ``grad`` (see include/gnc_hip.h); ``step`` is a device
+    int64 [1] counter advanced by the call, ``scratch`` a device float32 [2]."""
+    lib = load_library()
+    _require_cuda(param, grad, exp_avg, exp_avg_sq, step, scratch)
+    n = param.numel()
+    for t in (param, grad, exp_avg, exp_avg_sq):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != n:
+            raise ValueError("adam_step: flat contiguous float32 buffers of one size expected")
+    if step.dtype != torch.int64 or scratch.dtype != torch.float32 or scratch.numel() < 2:
+        raise ValueError("adam_step: step must be int64 [1], scratch float32 [2]")
+    with torch.cuda.device(param.device):
+        _check(_launch("adam_flat", param, lambda: lib.gnc_adam_step_f32(
+            param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), n, lr, beta1, beta2, eps, weight_decay,
+            step.data_ptr(), scratch.data_ptr(), _stream(param)), 28.0 * n), "gnc_adam_step_f32")

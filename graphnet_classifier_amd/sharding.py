@@ -37,40 +37,80 @@ def shard_ranges(edge_ptr, world_size: int):
     return [(cuts[r], cuts[r + 1]) for r in range(world_size)]
 
 
-class FlatGradAllReduce:
-    """Averages the gradients of ``params`` across ranks through one flat buffer."""
+def _world(group=None) -> int:
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
-    def __init__(self, params, group=None):
+
+class FlatGradAllReduce:
+    """Every parameter gradient as a VIEW of one flat fp32 buffer, and one collective over that buffer.
+
+    Protocol of a step (utils/train_model.py:40-42 with the collective inserted)::
+
+        reducer.zero_grad()      # p.grad = None: backward hands its freshly computed tensors over, no zero-fill,
+                                 # no per-parameter accumulate launch
+        loss.backward()
+        reducer()                # pack (ONE multi-tensor launch) + ONE all-reduce; afterwards p.grad IS the view
+        optimizer.step()         # reads p.grad = views of the flat buffer (a fused optimizer reads `flat` itself)
+
+    * zero copy out: after the call ``p.grad`` aliases ``flat``; nothing is copied back per parameter;
+    * the copy in is one ``torch._foreach_copy_`` over all parameters (one or two multi-tensor kernels, never a
+      ``copyBuffer`` per parameter); a gradient that autograd accumulated in place into last step's view (a caller
+      that skipped ``zero_grad``) is already in the buffer and is not touched;
+    * at world size 1 with ``pack_always=False`` the call returns at once (a true no-op);
+    * ``average=True`` divides by the world size after the SUM (gradient of the mean of per-rank mean losses).
+      Ranks with unequal graph counts (``shard_ranges`` balances by edges) should instead scale their LOCAL loss by
+      ``1 / global_graph_count`` (sum-reduced loss) and pass ``average=False``: the SUM of those gradients is exactly
+      the gradient of the global-batch mean loss.
+    """
+
+    def __init__(self, params, group=None, average: bool = True, pack_always: bool = False, flat: torch.Tensor | None = None):
         self.params = [p for p in params if p.requires_grad]
         self.group = group
+        self.average = average
+        self.pack_always = pack_always
         self.numel = sum(p.numel() for p in self.params)
         p0 = self.params[0]
-        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=p0.device)
-
-    def __call__(self) -> torch.Tensor:
-        """Call between backward() and optimizer.step(); returns the flat averaged buffer."""
-        off = 0
+        self.flat = flat if flat is not None else torch.zeros(self.numel, dtype=torch.float32, device=p0.device)
+        assert self.flat.numel() == self.numel and self.flat.dtype == torch.float32
+        self.views, off = [], 0
         for p in self.params:
-            n = p.numel()
-            if p.grad is None:
-                self.flat[off:off + n].zero_()
-            else:
-                self.flat[off:off + n].copy_(p.grad.reshape(-1))
-            off += n
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        self.collectives = 0  # number of all-reduce calls issued (tests assert one per step)
+
+    def zero_grad(self) -> None:
+        for p in self.params:
+            p.grad = None
+
+    def pack(self) -> torch.Tensor:
+        """Bring every gradient into the flat buffer and make ``p.grad`` the view of it."""
+        srcs, dsts = [], []
+        for p, v in zip(self.params, self.views):
+            g = p.grad
+            if g is None:
+                v.zero_()  # parameter unused by this step's graph
+            elif g.data_ptr() != v.data_ptr():
+                srcs.append(g if g.dtype == torch.float32 else g.float())
+                dsts.append(v)
+            p.grad = v
+        if srcs:
+            torch._foreach_copy_(dsts, srcs)
+        return self.flat
+
+    def __call__(self) -> torch.Tensor | None:
+        """Call between backward() and optimizer.step(); returns the flat (reduced) buffer."""
+        world = _world(self.group)
+        if world == 1 and not self.pack_always:
+            return None
+        self.pack()
+        if world > 1:
             if self.flat.is_cuda and dist.get_backend(self.group) == "gloo":  # CPU rehearsal backend: stage through the host
                 host = self.flat.cpu()
                 dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
                 self.flat.copy_(host)
             else:
                 dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)  # ONE collective per step (RCCL)
-            self.flat.div_(dist.get_world_size(self.group))
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            if p.grad is None:
-                p.grad = self.flat[off:off + n].view_as(p).clone()
-            else:
-                p.grad.copy_(self.flat[off:off + n].view_as(p))
-            off += n
+            self.collectives += 1
+            if self.average:
+                self.flat.div_(world)
         return self.flat

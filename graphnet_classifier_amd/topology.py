@@ -101,7 +101,9 @@ class TopologyCache:
     @staticmethod
     def _key(edge_index: torch.Tensor, num_nodes: int, device):
         if edge_index.is_cuda:
-            return ("dev", edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), num_nodes, str(device))
+            # shape alone does not pin the content: pairs.t() and pairs.view(2, E) share address, shape and version
+            return ("dev", edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), tuple(edge_index.stride()),
+                    str(edge_index.dtype), num_nodes, str(device))
         buf = edge_index.contiguous().numpy().tobytes()
         return ("host", hashlib.blake2b(buf, digest_size=16).digest(), tuple(edge_index.shape), str(edge_index.dtype),
                 num_nodes, str(device))
@@ -127,9 +129,57 @@ class TopologyCache:
 _default_cache = TopologyCache()
 
 
+class DestinationCSR:
+    """What the operator-level ``scatter_sum(src, index)`` needs and nothing more: the stable destination sort of ONE
+    index vector (``rowptr``, ``perm``) and, for its backward, the int32 copy of the index.  One host sync (the
+    out-of-range flag -> IndexError, as models/GNN.py:18-20's ``index_add_`` raises)."""
+
+    def __init__(self, index: torch.Tensor, num_nodes: int, device):
+        idx = index.to(device=device, dtype=torch.int64, non_blocking=True).contiguous()
+        self.num_nodes = int(num_nodes)
+        self.rowptr, self.perm, status = native.csr_build(idx, self.num_nodes)
+        self._index = idx
+        self._col32 = None
+        if int(status[0].item()):
+            raise IndexError(f"scatter_sum: index has entries outside [0, {self.num_nodes})")
+
+    @property
+    def col32(self) -> torch.Tensor:
+        if self._col32 is None:
+            self._col32 = native.permute_index(self._index, None)
+        return self._col32
+
+
+class _DestinationCache(TopologyCache):
+    """Keyed on the index vector itself (the public scatter_sum used to stack a fresh [2, E] tensor per call, which
+    could never hit the identity-keyed cache and pinned dead copies in the LRU)."""
+
+    def get(self, index: torch.Tensor, num_nodes: int, device) -> DestinationCSR:
+        key = self._key(index, num_nodes, device)
+        hit = self._entries.get(key)
+        if hit is not None:
+            self._entries.move_to_end(key)
+            self.hits += 1
+            return hit[0]
+        self.misses += 1
+        csr = DestinationCSR(index, num_nodes, device)
+        self._entries[key] = (csr, index if index.is_cuda else None)
+        while len(self._entries) > self.capacity:
+            self._entries.popitem(last=False)
+        return csr
+
+
+_destination_cache = _DestinationCache(capacity=4)
+
+
+def get_destination_csr(index: torch.Tensor, num_nodes: int, device) -> DestinationCSR:
+    return _destination_cache.get(index, num_nodes, device)
+
+
 def get_topology(edge_index: torch.Tensor, num_nodes: int, device) -> GraphTopology:
     return _default_cache.get(edge_index, num_nodes, device)
 
 
 def clear_topology_cache():
     _default_cache.clear()
+    _destination_cache.clear()

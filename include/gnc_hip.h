@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GNC_ABI_VERSION 12
+#define GNC_ABI_VERSION 13
 
 enum {
   GNC_OK = 0,
@@ -148,10 +148,11 @@ typedef struct gnc_mlp_segment {
   int32_t mode;         /* GNC_SEG_MATMUL | GNC_SEG_ADD                    */
   int32_t wcol;         /* MATMUL: first column of weight[0] this segment multiplies (segments may be
                            listed, i.e. staged, in any order; the concat order lives here)          */
-  int64_t table_rows;   /* rows of the table behind ptr = bound of the ids in `index`; 0 = not stated.
-                           With it (and a table below 4 GiB) the fast kernels gather through a
-                           bounds-checked buffer window: an id outside the table reads zeros instead of
-                           faulting.  Without it the flat-address kernels run.  Ignored when index==NULL */
+  int64_t table_rows;   /* rows of the table behind ptr = bound of the ids in `index`; REQUIRED (> 0) whenever
+                           index != NULL.  Every kernel variant treats an id outside [0, table_rows) the same
+                           way: the row reads as zeros, never a fault (tables below 4 GiB through the hardware
+                           bounds check of a buffer window, larger ones by an explicit compare).
+                           Ignored when index == NULL */
 } gnc_mlp_segment_t;
 
 typedef struct gnc_mlp_desc {
@@ -291,6 +292,18 @@ size_t gnc_rag_workspace_bytes(int32_t H, int32_t W);
 int gnc_rag_build(const int32_t* labels, const uint8_t* img, int32_t H, int32_t W, float* x, float* pos,
                   int64_t* edge_index, int64_t ld_edges, int32_t* counts, void* workspace, size_t workspace_bytes,
                   void* stream);
+
+/* ---- fused Adam over flat buffers -------------------------------
+ * Replaces `optimizer.step()` of utils/train_model.py:42 for `optim.Adam(model.parameters(), lr=1e-3)` (:9):
+ * every parameter is a view of `param` [n], every gradient a view of `grad` [n]; one launch updates all of them
+ * with torch.optim.Adam's arithmetic (amsgrad off).  `step` is a DEVICE int64 holding the number of updates made
+ * so far (the call advances it first; bias corrections are derived from it on the device in double precision), so
+ * the call sequence is the same on every step and can be replayed from a hipGraph.  `scratch2` is 2 floats of
+ * device scratch.  All four buffers 16-B aligned.
+ */
+int gnc_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                      float beta1, float beta2, float eps, float weight_decay, int64_t* step, float* scratch2,
+                      void* stream);
 
 #ifdef __cplusplus
 }

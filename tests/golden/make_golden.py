@@ -232,6 +232,94 @@ def image_graphs():
     _save("g7_image_graphs.npz", **arrays)
 
 
+def training_run():
+    """G8: the reference's own ``train()`` (utils/train_model.py:8-81) on a two-sample dataset that alternates two
+    images on ONE pixel-grid topology (8 x 8, the fixed-topology regime of image_to_graph_optimized.py:42-47):
+    8 epochs x 2 samples = 16 optimizer steps unless its early stopping (patience 2) ends the run sooner.  Recorded:
+    inputs, initial weights, the logits of every step (forward hook; the per-step loss follows from them and the
+    labels), the avg_loss lines the reference wrote to its log, the names of the .pth files it saved, and the final
+    weights (its final_model.pth)."""
+    import contextlib
+    import io
+    import tempfile
+    sys.path.insert(0, REF)
+    _register_metalayer()
+    from models.GNN import CombinedModel, GraphNet
+    from utils.image_to_graph.image_to_graph_optimized import create_grid_edges_optimized
+    from utils.train_model import train
+
+    torch.manual_seed(8)
+    kw = dict(num_local_features=3, space_dim=2, out_channels=1, n_blocks=2, out_dim_node=16, out_dim_edge=16,
+              hidden_dim_node=16, hidden_dim_edge=16, hidden_dim_decoder=16,
+              hidden_dim_processor_node=16, hidden_dim_processor_edge=16)
+    h = w = 8
+    ei = torch.from_numpy(create_grid_edges_optimized(h, w, False).astype(np.int64))
+    rr, cc = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    pos = torch.from_numpy(np.stack([rr.ravel(), cc.ravel()], 1).astype(np.float32))   # optimized.py:76-79
+    xs = [torch.rand(h * w, 3), torch.rand(h * w, 3)]
+    labels = [torch.tensor(0, dtype=torch.long), torch.tensor(1, dtype=torch.long)]
+    dataset = [((xs[0], pos, ei), labels[0]), ((xs[1], pos, ei), labels[1])]
+    m = CombinedModel(GraphNet(**kw), num_nodes=h * w, classes=2)
+    before = _sd(m, "before/")
+    step_logits = []
+    m.register_forward_hook(lambda mod, inp, out: step_logits.append(_np(out)))
+    epochs, patience = 8, 2
+    with tempfile.TemporaryDirectory() as tmp:
+        with contextlib.redirect_stdout(io.StringIO()):
+            train(m, dataset, epochs, patience=patience, output_path=tmp)
+        files = sorted(f for f in os.listdir(tmp) if f.endswith(".pth"))
+        log = [f for f in os.listdir(tmp) if f.startswith("training_logs_")]
+        assert len(log) == 1
+        with open(os.path.join(tmp, log[0])) as f:
+            lines = f.read().splitlines()
+        final = torch.load(os.path.join(tmp, "final_model.pth"), map_location="cpu", weights_only=True)
+    loss_lines = [l for l in lines if "avg_loss=" in l] + [l for l in lines if l.startswith("Best loss achieved")]
+    _save("g8_training_run.npz", x0=_np(xs[0]), x1=_np(xs[1]), pos=_np(pos), edge_index=_np(ei),
+          labels=np.array([0, 1], dtype=np.int64), epochs=np.array(epochs), patience=np.array(patience),
+          step_logits=np.stack(step_logits), log_lines=np.frombuffer("\n".join(loss_lines).encode(), dtype=np.uint8),
+          saved_files=np.frombuffer("\n".join(files).encode(), dtype=np.uint8),
+          kwargs_json=np.frombuffer(repr(kw).encode(), dtype=np.uint8), **before,
+          **{"after/" + k: _np(v) for k, v in final.items()})
+    print("G8:", len(step_logits), "steps;", files, loss_lines)
+
+    # second run: the early-stopping branch (:57-69).  The GraphNet runs above only ever improve, so the loop is
+    # driven by a scripted module (one dummy parameter, logits read from a list, input ignored): epoch losses go
+    # down, down, up, up -> with patience 2 the reference stops after epoch 4 of 10.
+    class Scripted(torch.nn.Module):
+        def __init__(self, seq):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(2))
+            self.seq, self.i = seq, 0
+
+        def forward(self, sample):
+            out = self.seq[self.i] + 0.0 * self.w
+            self.i += 1
+            return out
+
+    a = [0.0, 0.0, 0.5, 0.6, 0.2, 0.3, 0.3, 0.35, 0.9, 0.9, 0.9, 0.9]
+    seq = [torch.tensor([v, 0.0]) for v in a]
+    sm = Scripted(seq)
+    dataset = [(torch.zeros(3), torch.tensor(0)), (torch.zeros(3), torch.tensor(0))]
+    with tempfile.TemporaryDirectory() as tmp:
+        with contextlib.redirect_stdout(io.StringIO()) as out:
+            train(sm, dataset, 10, patience=2, output_path=tmp)
+        files = sorted(f for f in os.listdir(tmp) if f.endswith(".pth"))
+        log = [f for f in os.listdir(tmp) if f.startswith("training_logs_")]
+        with open(os.path.join(tmp, log[0])) as f:
+            lines = f.read().splitlines()
+    keep = [l for l in lines if "avg_loss=" in l or l.startswith("Best loss achieved") or l.startswith("Epochs:")]
+    stdout = [l for l in out.getvalue().splitlines() if l.startswith(("Early stopping", "Epoch "))]
+    _save("g8_early_stop.npz", logits_first=np.array(a, dtype=np.float32), epochs=np.array(10), patience=np.array(2),
+          steps_run=np.array(sm.i), log_lines=np.frombuffer("\n".join(keep).encode(), dtype=np.uint8),
+          saved_files=np.frombuffer("\n".join(files).encode(), dtype=np.uint8),
+          stdout_lines=np.frombuffer("\n".join(stdout).encode(), dtype=np.uint8))
+    print("G8b:", sm.i, "steps;", files, keep, stdout)
+
+
 if __name__ == "__main__":
-    main()
-    image_graphs()
+    if len(sys.argv) > 1 and sys.argv[1] == "g8":
+        training_run()
+    else:
+        main()
+        image_graphs()
+        training_run()

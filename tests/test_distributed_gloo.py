@@ -27,28 +27,66 @@ def _worker(rank, world, port, out_dir):
         from graphnet_classifier_amd.sharding import FlatGradAllReduce, shard_ranges
         from oracle import graphnet_oracle as O
 
-        # ---- one flat all-reduce averages every gradient ------------------------------------
+        # ---- one flat all-reduce averages every gradient; p.grad become views of the flat buffer (zero copy) ----
         torch.manual_seed(0)
-        model = CombinedModel(GraphNet(**S.graphnet_kwargs(16, 2)), num_nodes=12, classes=2).to("cpu")
-        for i, p in enumerate(model.parameters()):
+        model = CombinedModel(GraphNet(**S.graphnet_kwargs(16, 2)), num_nodes=144, classes=2).to("cpu")
+        params = list(model.parameters())
+        reducer = FlatGradAllReduce(params)
+        reducer.zero_grad()
+        assert all(p.grad is None for p in params)
+        for i, p in enumerate(params):
             p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
-        reducer = FlatGradAllReduce(model.parameters())
         flat = reducer()
-        assert flat.numel() == sum(p.numel() for p in model.parameters())
+        assert flat.numel() == sum(p.numel() for p in params) and reducer.collectives == 1
         mean_scale = sum(r + 1 for r in range(world)) / world
-        for i, p in enumerate(model.parameters()):
+        lo, hi = flat.data_ptr(), flat.data_ptr() + 4 * flat.numel()
+        for i, p in enumerate(params):
+            assert lo <= p.grad.data_ptr() < hi  # the gradient IS a slice of the flat buffer: nothing was copied back
             assert torch.allclose(p.grad, torch.full_like(p, mean_scale * (i + 1)))
         # identical Adam update on every rank afterwards
-        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        opt = torch.optim.Adam(params, lr=1e-3)
         opt.step()
-        digest = torch.stack([p.detach().double().sum() for p in model.parameters()]).sum().reshape(1)
+        digest = torch.stack([p.detach().double().sum() for p in params]).sum().reshape(1)
         gathered = [torch.zeros_like(digest) for _ in range(world)]
         dist.all_gather(gathered, digest)
         assert all(torch.equal(g, gathered[0]) for g in gathered)
 
+        # ---- unequal shards: SUM of (local sum-loss / global graph count) gradients == single-process mean-loss gradient
+        torch.manual_seed(1)
+        model = CombinedModel(GraphNet(**S.graphnet_kwargs(16, 2)), num_nodes=144, classes=2).to("cpu")
+        params = list(model.parameters())
+        named = dict(model.named_parameters())
+        batch = S.superpixel_like_graphs(5, seed=1000, shapes=((12, 12),))  # 5 graphs over 2 ranks: 2 / 3 or 3 / 2
+        labels = torch.tensor([0, 1, 1, 0, 1])
+        crit = torch.nn.CrossEntropyLoss(reduction="sum")
+        O.set_scatter_impl("index_add")  # differentiable restatement of models/GNN.py:18-20
+
+        def loss_of(g0, g1):
+            tot = 0.0
+            for gi in range(g0, g1):
+                sg = batch.slice_graphs(gi, gi + 1)
+                tot = tot + crit(O.combined_forward(named, sg.x, sg.pos, sg.edge_index).unsqueeze(0), labels[gi:gi + 1])
+            return tot / batch.num_graphs
+        g0, g1 = shard_ranges(batch.edge_ptr, world)[rank]
+        assert 0 < g1 - g0 < batch.num_graphs
+        reducer = FlatGradAllReduce(params, average=False)
+        reducer.zero_grad()
+        loss_of(g0, g1).backward()
+        reducer()
+        assert reducer.collectives == 1
+        sharded = [p.grad.clone() for p in params]
+        for p in params:
+            p.grad = None
+        loss_of(0, batch.num_graphs).backward()
+        for p, gs in zip(params, sharded):
+            assert torch.allclose(p.grad, gs, atol=1e-6, rtol=1e-4)
+        O.set_scatter_impl("sorted_loop")
+
         # ---- graph-id sharding reproduces the unsharded forward --------------------------------
         batch = S.superpixel_like_graphs(7, seed=1000)
         sd = {k: v.detach() for k, v in model.graph_net.state_dict().items()}
+        for p in params:
+            p.grad = None
         g0, g1 = shard_ranges(batch.edge_ptr, world)[rank]
         shard = batch.slice_graphs(g0, g1)
         y_local = O.graphnet_forward(sd, shard.x, shard.pos, shard.edge_index)

@@ -409,23 +409,30 @@ def test_batchnorm_norm_type_runs_through_the_kernel_plus_a_rocm_op(G):
 
 def test_bench_two_ranks_rehearsal_on_one_gpu(tmp_path):
     """bench.py's N > 1 bookkeeping (rank-local batches, barrier + max-over-ranks timing, summed units, one JSON
-    line on rank 0) with two ranks sharing this GPU over gloo; the real runs use RCCL, one rank per GPU."""
+    line on rank 0) with two ranks sharing this GPU over gloo; the real runs use RCCL, one rank per GPU.  The default
+    at N > 1 is BASELINE config c4 (the c3 graphs split by graph id, strong scaling) with a training leg whose step
+    holds exactly ONE collective."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, GNC_BENCH_BACKEND="gloo")
-    for extra, graphs in ((["--scaling", "weak"], 2 * 62), (["--scaling", "strong"], 62), (["--mode", "train"], 2 * 62)):
+    for extra, graphs, scaling in (([], 62, "strong"), (["--scaling", "weak"], 2 * 62, "weak"), (["--mode", "train"], 62, "strong")):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                "127.0.0.1", "--master-port", "29531", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup",
-               "1", "--scale", "0.01", "--no-cpu-baseline"] + extra
+               "1", "--scale", "0.01", "--no-cpu-baseline", "--train-steps", "2"] + extra
         out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
         lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
         assert out.returncode == 0 and len(lines) == 1, out.stderr[-2000:]
         d = json.loads(lines[0])
         assert d["n_gpus"] == 2 and d["config"]["graphs"] == graphs and d["value"] > 0
-        assert d["scaling"] == ("strong" if "strong" in extra else "weak")
+        assert d["scaling"] == scaling
+        if scaling == "strong":
+            assert d["config"]["workload"].startswith("c4:"), d["config"]["workload"]
+        tr = d["train"]
+        assert tr["collectives_per_step"] == 1.0 and tr["allreduce_ms"] > 0 and tr["value"] > 0
+        assert tr["allreduce_bytes"] >= 4 * 60_000
 
 
 def test_forward_on_cpu_module_fails_loudly(G):

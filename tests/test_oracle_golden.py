@@ -148,3 +148,37 @@ def test_superpixel_builder_restatement_on_a_label_image():
     assert pairs == set(und) | {(b, a) for a, b in und}
     assert ei[:, 0].tolist() == [0, 1] and ei[:, 1].tolist() == [1, 0]  # [i,j],[j,i] interleaved, lexicographic
     assert np.allclose(pos[0], [1 / 3, 1 / 3]) and np.allclose(x[0], img[seg == 0].mean(0) / 255.0)
+
+
+def test_g8_training_run_of_the_reference_is_reproduced_by_the_oracle():
+    """G8 (make_golden.py::training_run, the reference's own train()): 16 steps of forward (oracle) + CE + autograd
+    + torch.optim.Adam(lr=1e-3) from the recorded initial weights give the recorded per-step logits and final weights."""
+    import ast
+    g = load_golden("g8_training_run.npz")
+    sd = {k: v.clone().requires_grad_(True) for k, v in sub_state_dict(g, "before/").items()}
+    opt = torch.optim.Adam(list(sd.values()), lr=1e-3)
+    crit = torch.nn.CrossEntropyLoss()
+    pos, ei = t(g["pos"]), t(g["edge_index"])
+    xs = [t(g["x0"]), t(g["x1"])]
+    k = 0
+    O.set_scatter_impl("index_add")  # the differentiable restatement of models/GNN.py:18-20 (the edge-ordered loop detaches)
+    try:
+        _g8_steps(g, sd, opt, crit, xs, pos, ei)
+    finally:
+        O.set_scatter_impl("sorted_loop")
+    close = [float(((sd[n].detach() - t(g["after/" + n])).abs() < 2e-5).float().mean()) for n in sd]
+    assert min(close) > 0.9 and sum(close) / len(close) > 0.97
+
+
+def _g8_steps(g, sd, opt, crit, xs, pos, ei):
+    k = 0
+    for epoch in range(int(g["epochs"])):
+        for s_ in range(2):
+            logits = O.combined_forward(sd, xs[s_], pos, ei)
+            assert max_abs(logits.detach(), t(g["step_logits"][k])) < 1e-5, k
+            loss = crit(logits, torch.tensor(int(g["labels"][s_])))
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            k += 1
+    assert k == len(g["step_logits"])
