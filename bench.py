@@ -246,6 +246,7 @@ def main():
     for ev in marks:
         ev.record()  # allocate them now (re-recorded below)
     allocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)  # hipMalloc calls of the caching allocator so far
+    coll0 = train_ctx[0].reducer.collectives if train_ctx else 0
     t0 = time.perf_counter()
     marks[0].record()
     for k in range(a.steps):
@@ -301,7 +302,7 @@ def main():
         torch.cuda.synchronize()
         t_train, train_steps = elapsed, a.steps
         ar_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / max(1, len(evs))
-        collectives = flat_params.reducer.collectives
+        collectives = flat_params.reducer.collectives - coll0
     elif a.train_steps > 0:
         tstep, flat_params, ar_events = make_train_step()
         for _ in range(2):
