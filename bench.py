@@ -336,11 +336,15 @@ def main():
             wl_name = f"{a.workload}: {w['desc']}" + (f", one such batch per rank x {world}" if world > 1 else "")
         k1 = ksum.get("scatter_sum_csr_sorted") or ksum.get("scatter_sum_csr_perm")
         k1_gbps = k1["avg_work"] / (k1["avg_ms"] * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "k1_traffic.json")  # PMC-derived HBM bytes per launch, if collected
-        if os.path.exists(tpath):
-            with open(tpath) as f:
-                traffic = json.load(f).get(a.workload)
+        # HBM bytes per launch from PMC counters (FETCH_SIZE doubled + WRITE_SIZE, separate passes) of an EARLIER profiled
+        # run of this workload, condensed by tools/pmc_summary.py into profiles/pmc_<workload>.json
+        traffic = mlp_traffic = None
+        pmc_file = os.path.join("profiles", f"pmc_{a.workload}.json")
+        if a.scale == 1.0 and world == 1 and os.path.exists(os.path.join(ROOT, pmc_file)):
+            with open(os.path.join(ROOT, pmc_file)) as f:
+                pmc = json.load(f)
+            traffic = pmc["kernels"].get(pmc.get("k1", ""), {}).get("hbm_bytes_per_launch")
+            mlp_traffic = pmc["kernels"].get(pmc.get("dominant_mlp", ""), {}).get("hbm_bytes_per_launch")
         mlp_name = max((k for k in ksum if k.startswith("mlp_fused")), key=lambda k: ksum[k]["avg_ms"] * ksum[k]["launches"])
         mlp = ksum[mlp_name]
         mlp_tflops = mlp["avg_work"] / (mlp["avg_ms"] * 1e-3) / 1e12
@@ -362,7 +366,7 @@ def main():
                          if k1_isolated else "every K1 launch of the timed region",
                          "bound": "hbm", "achieved": k1_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": k1_gbps / HBM_PEAK_GBPS, "traffic": traffic,
-                         "traffic_source": "PMC counters of an earlier run of this kernel at this size, kept under profiles/ "
+                         "traffic_source": f"{pmc_file}: PMC counters of an earlier profiled run of this workload "
                                            "(not measured in this run)" if traffic is not None else None,
                          "avg_launch_ms": k1["avg_ms"], "launches": k1["launches"],
                          "algorithmic_bytes_per_launch": k1["avg_work"]},
@@ -370,6 +374,15 @@ def main():
                              "bound": "mfma", "achieved": mlp_tflops, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": mlp_tflops / MFMA_F32_PEAK_TFLOPS, "avg_launch_ms": mlp["avg_ms"],
                              "launches": mlp["launches"], "executed_flops_per_launch": mlp["avg_work"],
+                             # HBM side of the same launch: rows in (4 D E), rows out (4 D E), and for the W-split edge launch the
+                             # two gathered projections priced as if every gathered row came from memory (2 x 4 D E; the tables
+                             # are 4 D N each and mostly L2 / MALL resident), three int32 ids per edge and the aggregate (4 D N)
+                             "algorithmic_bytes_per_launch": (4.0 * w["width"] * (4 * batch.num_edges + batch.num_nodes) + 12.0 * batch.num_edges)
+                             if "+2add" in mlp_name else None,
+                             "traffic": mlp_traffic if "+2add" in mlp_name else None,
+                             "traffic_over_algorithmic": (mlp_traffic / (4.0 * w["width"] * (4 * batch.num_edges + batch.num_nodes) + 12.0 * batch.num_edges))
+                             if (mlp_traffic and "+2add" in mlp_name) else None,
+                             "traffic_source": (f"{pmc_file} (earlier profiled run, not this one)" if mlp_traffic else None),
                              # the reference's concat form of the same launch (W-split removes 2 of the 3 first-Linear blocks)
                              "reference_form_flops_per_launch": mlp["avg_work"] + (4.0 * batch.num_edges * w["width"] ** 2
                                                                                     if "+2add" in mlp_name else 0.0)},
