@@ -6,8 +6,8 @@ The FAST kernels issue their output stores from inline asm so that hipcc's `vmcn
 from the compiler.  This script re-establishes them on the built code objects (gfx950 disassembly of every
 build/csrc/*.o):
 
-  (a) drained waits: `s_waitcnt vmcnt(0)` inside a kernel's MAIN loop (the largest backward-branch range = the
-      persistent tile loop) may not exceed the recorded budget - a new one means some change made the compiler give
+  (a) drained waits: `s_waitcnt vmcnt(0)` inside a kernel's MAIN loop (the smallest backward-branch range that holds
+      90 % of its matrix instructions = the persistent tile loop) may not exceed the recorded budget - a new one means some change made the compiler give
       up counted waits again and every prefetch of that tile is drained at that point;
   (b) SGPR hazard: a VMEM instruction (buffer_/global_/flat_/scratch_ load or store) that reads an SGPR written by a
       VALU instruction (`v_readlane_b32` / `v_readfirstlane_b32`: SGPR-spill restores, wave-uniform values) needs 5
@@ -110,7 +110,11 @@ def analyse_object(obj, tmp):
                     tgt = base + int(m.group(1), 16) if m else (base if tgt_txt else None)
                     if tgt is not None and tgt <= addr:
                         loops.append((tgt, addr))
-            main = max(loops, key=lambda r: r[1] - r[0]) if loops else None
+            mf = [x[0] for x in ins if x[1].startswith("v_mfma")]
+            cover = [l for l in loops if mf and sum(1 for m_ in mf if l[0] <= m_ <= l[1]) >= 0.9 * len(mf)]
+            # the persistent tile loop: the SMALLEST backward-branch range holding >= 90 % of the kernel's matrix
+            # instructions (kernels without MFMAs: the largest range)
+            main = (min(cover, key=lambda r: r[1] - r[0]) if cover else max(loops, key=lambda r: r[1] - r[0])) if loops else None
             vm0 = sum(1 for addr, op, args, _ in ins if main and main[0] <= addr <= main[1] and op == "s_waitcnt"
                       and re.search(r"vmcnt\(0\)", args))
             # hazard (b)
