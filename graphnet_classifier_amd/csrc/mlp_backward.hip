@@ -100,18 +100,6 @@ __device__ __forceinline__ void tile_from_lds(f32x16 (&acc)[T], const float* abu
     }
 }
 
-struct BwdArgs {
-  const float* grad_out;
-  int ld_grad_out;
-  float* act[GNC_MAX_LINEAR];  // [rows, H] post-activation outputs of layers 0 .. L-2
-  float* dz[GNC_MAX_LINEAR];   // [rows, width_l] grad wrt the pre-activation of layer l (l = L-1: pre-LayerNorm)
-  float* dx;                   // nullable: [rows, in_dim0] grad wrt the MATMUL part of the input
-  int ld_dx;
-  float* yhat;                 // [rows, out_dim] normalised pre-affine output (only with LayerNorm)
-  int dx_add_grad_out;         // add grad_out rows to dx (the residual path of a segment that is also the residual)
-  float* ln_partial;           // nullable: [waves, 2 * out_dim] per-wave [colsum(grad_out) | colsum(grad_out * yhat)]
-};
-
 // HT = tiles of the hidden AND output width (both <= 64).  NMM / NADD as in mlp_resident.hip.
 template <int HT, int NMM, int NADD>
 __global__ __launch_bounds__(BNT) void mlp_backward_data_kernel(const gnc_mlp_desc_t d, const BwdArgs b,
@@ -931,9 +919,12 @@ template <int TM, int TK>
 __global__ __launch_bounds__(256) void xty_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
                                                   int64_t ldb, int rows, int M, int K, float* __restrict__ partial,
                                                   int pstride) {
-  // Rows arrive as whole 16-B pieces (coalesced), are parked in a wave-private LDS tile and are read back
-  // down the columns (ds_read_b32) as MFMA operands: lane (i, h) of step s needs row 2s+h, column 32t+i.
-  __shared__ __attribute__((aligned(16))) float tiles[4][2][RPW * LDSW];
+  // Rows arrive as whole 16-B pieces (coalesced), are parked in wave-private LDS tiles (one [32][64] tile per 64
+  // columns of an operand) and are read back down the columns (ds_read_b32) as MFMA operands: lane (i, h) of step s
+  // needs row 2s+h, column 32t+i.  TM, TK = 32-column blocks of A and B (1, 2 or 4: operands up to 128 columns, so a
+  // 256 x 256 weight gradient is four launches that each read their two [rows, 128] slabs once).
+  extern __shared__ __attribute__((aligned(16))) float xty_lds[];
+  constexpr int NA = (TM + 1) / 2, NB = (TK + 1) / 2;  // 64-column LDS tiles per operand
   const int lane = threadIdx.x & 63;
   const int i = lane & 31;
   const int h = lane >> 5;
@@ -942,8 +933,8 @@ __global__ __launch_bounds__(256) void xty_kernel(const float* __restrict__ A, i
   const int wave = ((int)blockIdx.x * (int)blockDim.x + (int)threadIdx.x) >> 6;
   const int total_waves = ((int)gridDim.x * (int)blockDim.x) >> 6;
   const int num_tiles = (rows + RPW - 1) / RPW;
-  float* ta = tiles[wib][0];
-  float* tb = tiles[wib][1];
+  float* ta = xty_lds + wib * (NA + NB) * RPW * LDSW;
+  float* tb = ta + NA * RPW * LDSW;
   const bool avec = (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15u) == 0);
   const bool bvec = (ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(B) & 15u) == 0);
   f32x16 acc[TM][TK];
@@ -957,9 +948,10 @@ __global__ __launch_bounds__(256) void xty_kernel(const float* __restrict__ A, i
 #pragma unroll
   for (int a = 0; a < TM; ++a) csum[a] = 0.f;
 
-  auto load_tile = [&](f32x4 (&pre)[NP], const float* base, int64_t ld, int width, bool vec, int tile) {
-    const int col = c4 * 4;
-    if (vec && width == KC) {  // full-width operand: one buffer window per tile, rows past the end read as 0
+  // columns [c0, c0 + 64) of the operand, zero beyond `width` (the operand's total column count)
+  auto load_tile = [&](f32x4 (&pre)[NP], const float* base, int64_t ld, int width, int c0, bool vec, int tile) {
+    const int col = c0 + c4 * 4;
+    if (vec && c0 + KC <= width) {  // full slab: one buffer window per tile, rows past the end read as 0
       load_tile_rows<true>(pre, base, (int)ld, (int64_t)tile * RPW, rows, (uint32_t)(rs * (int)ld + col) * 4u);
       return;
     }
@@ -984,33 +976,39 @@ __global__ __launch_bounds__(256) void xty_kernel(const float* __restrict__ A, i
   };
 
   int tile = wave;
-  f32x4 pa[NP], pb[NP];
+  f32x4 pa[NA][NP], pb[NB][NP];
   if (tile < num_tiles) {
-    load_tile(pa, A, lda, M, avec, tile);
-    load_tile(pb, B, ldb, K, bvec, tile);
+#pragma unroll
+    for (int u = 0; u < NA; ++u) load_tile(pa[u], A, lda, M, u * KC, avec, tile);
+#pragma unroll
+    for (int u = 0; u < NB; ++u) load_tile(pb[u], B, ldb, K, u * KC, bvec, tile);
   }
   for (; tile < num_tiles; tile += total_waves) {
     compiler_lds_barrier();
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-      *reinterpret_cast<f32x4*>(ta + (p * 4 + rs) * LDSW + c4 * 4) = pa[p];
-      *reinterpret_cast<f32x4*>(tb + (p * 4 + rs) * LDSW + c4 * 4) = pb[p];
+#pragma unroll
+      for (int u = 0; u < NA; ++u) *reinterpret_cast<f32x4*>(ta + u * RPW * LDSW + (p * 4 + rs) * LDSW + c4 * 4) = pa[u][p];
+#pragma unroll
+      for (int u = 0; u < NB; ++u) *reinterpret_cast<f32x4*>(tb + u * RPW * LDSW + (p * 4 + rs) * LDSW + c4 * 4) = pb[u][p];
     }
     compiler_lds_barrier();
     const int nt = tile + total_waves;  // next tile's rows fly while this one is multiplied (clamped: always legal)
-    load_tile(pa, A, lda, M, avec, nt < num_tiles ? nt : num_tiles - 1);
-    load_tile(pb, B, ldb, K, bvec, nt < num_tiles ? nt : num_tiles - 1);
-    // (the windowed path would also be legal past the end; clamping keeps both paths on one schedule)
-#pragma unroll 4
+    const int ntc = nt < num_tiles ? nt : num_tiles - 1;
+#pragma unroll
+    for (int u = 0; u < NA; ++u) load_tile(pa[u], A, lda, M, u * KC, avec, ntc);
+#pragma unroll
+    for (int u = 0; u < NB; ++u) load_tile(pb[u], B, ldb, K, u * KC, bvec, ntc);
+#pragma unroll 2
     for (int s = 0; s < RPW / 2; ++s) {
       float av[TM], bv[TK];
 #pragma unroll
       for (int a = 0; a < TM; ++a) {
-        av[a] = ta[(2 * s + h) * LDSW + 32 * a + i];
+        av[a] = ta[(a >> 1) * RPW * LDSW + (2 * s + h) * LDSW + 32 * (a & 1) + i];
         csum[a] += av[a];
       }
 #pragma unroll
-      for (int c = 0; c < TK; ++c) bv[c] = tb[(2 * s + h) * LDSW + 32 * c + i];
+      for (int c = 0; c < TK; ++c) bv[c] = tb[(c >> 1) * RPW * LDSW + (2 * s + h) * LDSW + 32 * (c & 1) + i];
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -1204,6 +1202,14 @@ int bwd_grid(int64_t rows) {
 
 }  // namespace
 
+namespace {
+// widths 129..256: the 16-row kernel of mlp_backward16.hip (GNC_NO_BACKWARD16=1 switches it off for A/B runs)
+bool use_stream16(const gnc_mlp_desc_t& d, bool want_dx) {
+  static const bool off = getenv("GNC_NO_BACKWARD16") != nullptr;
+  return !off && bwd_stream16_supported(d, want_dx);
+}
+}  // namespace
+
 extern "C" size_t gnc_sizeof_mlp_bwd_desc(void) { return sizeof(gnc_mlp_bwd_desc_t); }
 
 extern "C" int gnc_mlp_backward_supported(const gnc_mlp_desc_t* fwd) {
@@ -1211,8 +1217,8 @@ extern "C" int gnc_mlp_backward_supported(const gnc_mlp_desc_t* fwd) {
   if (rc) return rc;
   int nmm, nadd, T;
   BwdPlan pl;
-  if (!bwd_shape(*fwd, &nmm, &nadd, &T) && !bwd_stream_plan(*fwd, true, &pl, &T)) {
-    gnc::set_error("gnc_mlp_backward: shape outside the HIP backward kernels (needs ReLU, widths <= 128, aligned tables)");
+  if (!bwd_shape(*fwd, &nmm, &nadd, &T) && !bwd_stream_plan(*fwd, true, &pl, &T) && !use_stream16(*fwd, true)) {
+    gnc::set_error("gnc_mlp_backward: shape outside the HIP backward kernels (needs ReLU, widths <= 256, aligned tables)");
     return GNC_ERR_UNSUPPORTED;
   }
   return GNC_OK;
@@ -1293,7 +1299,9 @@ extern "C" int gnc_mlp_backward_f32(const gnc_mlp_bwd_desc_t* bd, void* stream_)
     return fn == 2 ? launch_fused<2>(d, fb, fo, (hipStream_t)stream_) : launch_fused<0>(d, fb, fo, (hipStream_t)stream_);
   }
   const bool resident = bwd_shape(d, &nmm, &nadd, &T);
-  if (!resident && !bwd_stream_plan(d, bd->dx != nullptr, &pl, &T)) {
+  const bool stream32 = !resident && bwd_stream_plan(d, bd->dx != nullptr, &pl, &T);
+  const bool stream16 = !resident && !stream32 && use_stream16(d, bd->dx != nullptr);
+  if (!resident && !stream32 && !stream16) {
     gnc::set_error("gnc_mlp_backward_f32: shape outside the HIP backward kernels");
     return GNC_ERR_UNSUPPORTED;
   }
@@ -1319,6 +1327,7 @@ extern "C" int gnc_mlp_backward_f32(const gnc_mlp_bwd_desc_t* bd, void* stream_)
   b.dx_add_grad_out = (resident && bd->dx_add_grad_out) ? 1 : 0;
   b.ln_partial = (resident && d.ln_gamma) ? bd->ln_partial : nullptr;
 
+  if (stream16) return launch_bwd_stream16(d, b, (hipStream_t)stream_);
   if (!resident) {
     hipStream_t st = (hipStream_t)stream_;
     switch (T) {
@@ -1367,21 +1376,40 @@ extern "C" int gnc_xty_partials(int64_t rows) {
   return (int)waves;
 }
 
+namespace {
+template <int TM, int TK>
+int launch_xty(const float* A, int64_t lda, const float* B, int64_t ldb, int rows, int M, int K, float* partial, int waves,
+               hipStream_t stream) {
+  constexpr int NA = (TM + 1) / 2, NB = (TK + 1) / 2;
+  constexpr size_t smem = (size_t)4 * (NA + NB) * RPW * LDSW * sizeof(float);
+  static_assert(smem <= 160 * 1024, "xty: LDS budget");
+  static bool attr_set = false;
+  if (!attr_set) {
+    int rc = gnc::check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&xty_kernel<TM, TK>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                            "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    if (rc) return rc;
+    attr_set = true;
+  }
+  xty_kernel<TM, TK><<<dim3((unsigned)(waves / 4)), dim3(256), smem, stream>>>(A, lda, B, ldb, rows, M, K, partial, M * K + M);
+  return gnc::check_launch("xty_kernel");
+}
+inline int blocks32(int w) { return w <= 32 ? 1 : w <= 64 ? 2 : 4; }
+}  // namespace
+
 extern "C" int gnc_xty_f32(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t rows, int32_t M, int32_t K,
                            float* partial, int32_t num_partials, void* stream_) {
-  GNC_REQUIRE(rows >= 1 && rows < INT32_MAX && M >= 1 && K >= 1 && M <= 64 && K <= 64, "gnc_xty_f32: need 1 <= M, K <= 64");
+  GNC_REQUIRE(rows >= 1 && rows < INT32_MAX && M >= 1 && K >= 1 && M <= 128 && K <= 128, "gnc_xty_f32: need 1 <= M, K <= 128");
   GNC_REQUIRE(A && B && partial && lda >= M && ldb >= K, "gnc_xty_f32: null pointer or leading dimension too small");
   const int waves = gnc_xty_partials(rows);
   GNC_REQUIRE(num_partials >= waves, "gnc_xty_f32: partial buffer smaller than gnc_xty_partials()");
   hipStream_t stream = (hipStream_t)stream_;
-  const int pstride = M * K + M;
-  dim3 grid((unsigned)(waves / 4)), block(256);
-  const int tm = M > 32 ? 2 : 1, tk = K > 32 ? 2 : 1;
-  if (tm == 2 && tk == 2) xty_kernel<2, 2><<<grid, block, 0, stream>>>(A, lda, B, ldb, (int)rows, M, K, partial, pstride);
-  else if (tm == 2) xty_kernel<2, 1><<<grid, block, 0, stream>>>(A, lda, B, ldb, (int)rows, M, K, partial, pstride);
-  else if (tk == 2) xty_kernel<1, 2><<<grid, block, 0, stream>>>(A, lda, B, ldb, (int)rows, M, K, partial, pstride);
-  else xty_kernel<1, 1><<<grid, block, 0, stream>>>(A, lda, B, ldb, (int)rows, M, K, partial, pstride);
-  return gnc::check_launch("xty_kernel");
+  const int tm = blocks32(M), tk = blocks32(K);
+#define GNC_XTY(TM_, TK_) if (tm == TM_ && tk == TK_) return launch_xty<TM_, TK_>(A, lda, B, ldb, (int)rows, M, K, partial, waves, stream)
+  GNC_XTY(1, 1); GNC_XTY(1, 2); GNC_XTY(1, 4); GNC_XTY(2, 1); GNC_XTY(2, 2); GNC_XTY(2, 4); GNC_XTY(4, 1); GNC_XTY(4, 2); GNC_XTY(4, 4);
+#undef GNC_XTY
+  gnc::set_error("gnc_xty_f32: no instance for M = %d, K = %d", M, K);
+  return GNC_ERR_UNSUPPORTED;
 }
 
 extern "C" int gnc_colsum_pair_f32(const float* G, int64_t ldg, const float* Y, int64_t ldy, int64_t rows, int32_t width,

@@ -1,0 +1,535 @@
+// K8 data kernel for widths 129..256: the 16-row formulation of mlp_stream16.hip run backwards.
+//
+// Same contract as mlp_backward_stream_kernel (mlp_backward.hip: recompute the forward of the tile, LayerNorm backward,
+// da_l = W_{l+1}^T dz_{l+1}, dz_l = da_l * (a_l > 0), dx = W_0^T dz_0; emits a_l, dz_l, y_hat, dx as whole rows), but
+// at 256 features the 32-row form would need four 128-register accumulator sets.  With v_mfma_f32_16x16x4_f32 a wave
+// owns 16 data rows, one set is 64 registers, the two live ones (hid / next going forward, dz / da going backward) fit
+// next to the weight-chunk prefetch, and 8 waves run per CU.  Post-activation tensors leave the kernel as soon as they
+// are formed; what stays of them is one bit per value (the ReLU mask).
+//
+// Transposed products.  Accumulator register s of tile t on lane (i = lane & 15, g = lane >> 4) holds feature
+// n = 16t + 4g + s of data row i, which is the B operand (k slot g) of an MFMA whose A operand is
+// W[n][64c + 16cb + i]: read down a column of the staged [n][64 k] chunk (ds_read_b32, the four lane groups hit
+// four different banks groups: conflict-free with the 68-float row pitch).  The chunk sequence of a tile - forward
+// chunks, the last Linear for the LayerNorm statistics, then the same chunks in reverse layer order, then the first
+// Linear's again for dx - streams through the single 70 KB LDS buffer exactly as in the forward kernel (register
+// prefetch under the MFMAs of the previous chunk, two barriers per chunk).
+#include <stdlib.h>
+
+#include "mlp_device16.h"
+
+using namespace gnc_mlp;
+
+namespace {
+
+constexpr int B16_MAX_STEPS = 16;
+constexpr int B16_MAX_WCHUNKS = 72;
+
+struct BPlan16 {
+  int num_steps;    // first-Linear staging steps per tile
+  int num_wchunks;  // weight chunks per tile (forward + backward + dx)
+  struct { short seg, c0, add, pad; } step[B16_MAX_STEPS];
+  struct { short layer, kbase, klimit, pad; } wc[B16_MAX_WCHUNKS];
+};
+
+// ReLU in place; bit (4 * (t % 8) + r) of m[t / 8] = value was positive
+template <int NTL>
+__device__ __forceinline__ void relu_mask16(f32x4 (&acc)[NTL], unsigned (&m)[(NTL + 7) / 8]) {
+#pragma unroll
+  for (int w = 0; w < (NTL + 7) / 8; ++w) {
+    unsigned bits = 0;
+#pragma unroll
+    for (int tt = 0; tt < 8; ++tt) {
+      const int t = 8 * w + tt;
+      if (t < NTL) {
+        float* v = reinterpret_cast<float*>(&acc[t < NTL ? t : 0]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool pos = v[r] > 0.f;
+          bits |= pos ? (1u << (4 * tt + r)) : 0u;
+          v[r] = pos ? v[r] : 0.f;
+        }
+      }
+    }
+    m[w] = bits;
+  }
+}
+
+template <int NTL>
+__device__ __forceinline__ void apply_mask16(f32x4 (&acc)[NTL], const unsigned (&m)[(NTL + 7) / 8]) {
+#pragma unroll
+  for (int t = 0; t < NTL; ++t) {
+    float* v = reinterpret_cast<float*>(&acc[t]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = (m[t / 8] >> (4 * (t % 8) + r)) & 1u ? v[r] : 0.f;
+  }
+}
+
+// dst[DBASE + cb] += (columns [16 cb, 16 cb + 16) of the staged chunk)^T * src for cb = 0..3: contraction over the
+// chunk's rows n (the NTI tiles of src)
+template <int NTI, int NTO, int DBASE>
+__device__ __forceinline__ void mma16_transposed_chunk(f32x4 (&dst)[NTO], const f32x4 (&src)[NTI], const float* wbuf, int i,
+                                                       int g) {
+  const float* col = wbuf + (4 * g) * LDSW + i;
+#pragma unroll
+  for (int t = 0; t < NTI; ++t) {
+    const float bs[4] = {src[t].x, src[t].y, src[t].z, src[t].w};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) {
+        if constexpr (DBASE + 3 < NTO) {
+          dst[DBASE + cb] = mfma16(col[(16 * t + s) * LDSW + 16 * cb], bs[s], dst[DBASE + cb]);
+        }
+      }
+    }
+    if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // a bounded window of column reads in flight
+  }
+}
+
+// LayerNorm backward on the 16-row accumulator layout (see layer_norm_backward_tiles in mlp_device.h):
+//   in : y = pre-LayerNorm output (features >= out_dim exact zeros), gr = grad wrt the LayerNorm output
+//   out: y = y_hat (normalised, pre-affine), gr = grad wrt the pre-LayerNorm output
+template <int NTL>
+__device__ __forceinline__ void layer_norm_backward16(f32x4 (&y)[NTL], f32x4 (&gr)[NTL], const float* pg, int out_dim, float eps,
+                                                      int g) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const float inv_n = 1.f / (float)out_dim;
+  const bool padded = out_dim != NTL * 16;
+  f32x2 sa = {0.f, 0.f}, sb = {0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < NTL; ++t) {
+    sa += f32x2{y[t].x, y[t].y};
+    sb += f32x2{y[t].z, y[t].w};
+  }
+  const float mean = add_quarters((sa.x + sa.y) + (sb.x + sb.y)) * inv_n;
+  const f32x4 m4 = {mean, mean, mean, mean};
+#pragma unroll
+  for (int t = 0; t < NTL; ++t) y[t] -= m4;
+  if (padded) {
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) {
+      const int f = 16 * t + 4 * g;
+      y[t].x = f + 0 < out_dim ? y[t].x : 0.f; y[t].y = f + 1 < out_dim ? y[t].y : 0.f;
+      y[t].z = f + 2 < out_dim ? y[t].z : 0.f; y[t].w = f + 3 < out_dim ? y[t].w : 0.f;
+      gr[t].x = f + 0 < out_dim ? gr[t].x : 0.f; gr[t].y = f + 1 < out_dim ? gr[t].y : 0.f;
+      gr[t].z = f + 2 < out_dim ? gr[t].z : 0.f; gr[t].w = f + 3 < out_dim ? gr[t].w : 0.f;
+    }
+  }
+  f32x2 va = {0.f, 0.f}, vb = {0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < NTL; ++t) {
+    const f32x2 da = {y[t].x, y[t].y}, db = {y[t].z, y[t].w};
+    va = __builtin_elementwise_fma(da, da, va);
+    vb = __builtin_elementwise_fma(db, db, vb);
+  }
+  const float rstd = __frsqrt_rn(add_quarters((va.x + va.y) + (vb.x + vb.y)) * inv_n + eps);
+  const f32x4 r4 = {rstd, rstd, rstd, rstd};
+  f32x4 m1v = {0.f, 0.f, 0.f, 0.f}, m2v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < NTL; ++t) {
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(pg + 16 * t + 4 * g);  // gamma, zero padded
+    y[t] = y[t] * r4;        // y_hat
+    gr[t] = gr[t] * gm;      // g * gamma
+    m1v += gr[t];
+    m2v = __builtin_elementwise_fma(gr[t], y[t], m2v);
+  }
+  const float m1 = add_quarters((m1v.x + m1v.y) + (m1v.z + m1v.w)) * inv_n;
+  const float m2 = add_quarters((m2v.x + m2v.y) + (m2v.z + m2v.w)) * inv_n;
+  const f32x4 nm1 = {-m1, -m1, -m1, -m1}, nm2 = {-m2, -m2, -m2, -m2};
+#pragma unroll
+  for (int t = 0; t < NTL; ++t) gr[t] = __builtin_elementwise_fma(y[t], nm2, gr[t] + nm1) * r4;  // rstd * (g - m1 - y_hat * m2)
+  if (padded) {
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) {
+      const int f = 16 * t + 4 * g;
+      gr[t].x = f + 0 < out_dim ? gr[t].x : 0.f; gr[t].y = f + 1 < out_dim ? gr[t].y : 0.f;
+      gr[t].z = f + 2 < out_dim ? gr[t].z : 0.f; gr[t].w = f + 3 < out_dim ? gr[t].w : 0.f;
+    }
+  }
+}
+
+// NTL: 16-feature tiles of the widest layer (hidden / output): 16 for 129..256 features
+template <int NTL>
+__global__ __launch_bounds__(NT16) void mlp_backward_stream16_kernel(const gnc_mlp_desc_t d, const BwdArgs b, const BPlan16 pl,
+                                                                      const int num_tiles) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int WROWS = NTL * 16;
+  constexpr int CH = WROWS * LDSW;
+  constexpr int PSTRIDE = WROWS;
+  constexpr int RPP = NT16 / 16;
+  constexpr int NW = WROWS / RPP;
+  constexpr int NCH = (NTL + 3) / 4;
+  constexpr int MW = (NTL + 7) / 8;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15;
+  const int g = lane >> 4;
+  const int c4 = lane & 15;
+  const int rs = lane >> 4;
+  const int wc4 = tid & 15;
+  const int wr0 = tid >> 4;
+  const int L = d.num_linear;
+  const int out_dim = d.out_dim[L - 1];
+  const int rows = (int)d.rows;
+  float* wbuf = lds;
+  float* pbuf = lds + CH;
+  float* abuf = pbuf + (L + 2) * PSTRIDE + wave * R16 * LDSW;
+
+  stage_params<NT16>(pbuf, d, PSTRIDE, tid);
+
+  auto wload = [&](f32x4 (&wr)[NW], int q) {
+    const int layer = pl.wc[q].layer;
+    const float* W = d.weight[layer];
+    const int ldw = ldw_of(d, layer);
+    const int nrows = d.out_dim[layer];
+    const int klimit = pl.wc[q].klimit;
+    const int kbase = pl.wc[q].kbase;
+    if (kbase + KC <= klimit && (int64_t)nrows * ldw * 4 <= 0xffffffffll) {
+      // full 64-column chunk (the plan guarantees aligned weights): window over the matrix, rows >= nrows read as 0
+      const __amdgpu_buffer_rsrc_t w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, nrows * ldw * 4, 0x00020000);
+      const uint32_t off0 = (uint32_t)(wr0 * ldw + kbase + wc4 * 4) * 4u;
+#pragma unroll
+      for (int p = 0; p < NW; ++p) wr[p] = window_load(w, off0 + (uint32_t)(p * RPP * 4) * (uint32_t)ldw);
+      return;
+    }
+    const int col = kbase + wc4 * 4;
+    const int colc = col < klimit ? col : kbase;
+#pragma unroll
+    for (int p = 0; p < NW; ++p) {
+      const int n = p * RPP + wr0;
+      const int nc = n < nrows ? n : nrows - 1;
+      f32x4 v = *reinterpret_cast<const f32x4*>(W + (int64_t)nc * ldw + colc);
+      const bool rowok = n < nrows;
+      v.x = (rowok && col + 0 < klimit) ? v.x : 0.f; v.y = (rowok && col + 1 < klimit) ? v.y : 0.f;
+      v.z = (rowok && col + 2 < klimit) ? v.z : 0.f; v.w = (rowok && col + 3 < klimit) ? v.w : 0.f;
+      wr[p] = v;
+    }
+  };
+  auto wstore = [&](const f32x4 (&wr)[NW]) {
+#pragma unroll
+    for (int p = 0; p < NW; ++p) *reinterpret_cast<f32x4*>(wbuf + (p * RPP + wr0) * LDSW + wc4 * 4) = wr[p];
+  };
+  const int last_tile = num_tiles - 1;
+  auto load_idx = [&](int tile, int s) -> int {
+    const int tc = tile < last_tile ? tile : last_tile;
+    int r = (tc * W16 + wave) * R16 + (lane & 15);
+    r = r < rows ? r : rows - 1;
+    const int32_t* ip = d.seg[s].index;
+    return ip ? ip[r] : r;
+  };
+  // rows of one 64-column slab of a table: row-ordered tables through a window at the wave's first row (rows past the
+  // end read 0), gathered tables through a window over the stated table (< 4 GiB: guaranteed by the support query)
+  auto load_rows = [&](f32x4 (&pre)[NP16], const float* base, int ld, const int32_t* index, int64_t table_rows, int c0, int idxv,
+                       int tile_of) {
+    const int col = c0 + c4 * 4 < ld ? c0 + c4 * 4 : 0;
+    if (index == nullptr) {
+      load_tile_rows<false, NP16>(pre, base, ld, ((int64_t)tile_of * W16 + wave) * R16, rows, (uint32_t)(rs * ld + col) * 4u);
+    } else {
+      const __amdgpu_buffer_rsrc_t w =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)(uint32_t)(table_rows * (int64_t)ld * 4), 0x00020000);
+      const int row_bytes = idxv * (ld * 4);
+#pragma unroll
+      for (int p = 0; p < NP16; ++p) pre[p] = window_load(w, (uint32_t)__shfl(row_bytes, p * 4 + rs, 64) + (uint32_t)(col * 4));
+    }
+  };
+  auto stage = [&](const f32x4 (&pre)[NP16], int c0, int width) {
+    compiler_lds_barrier();
+    const int c = c0 + c4 * 4;
+    if (c0 + KC <= width) {
+#pragma unroll
+      for (int p = 0; p < NP16; ++p) *reinterpret_cast<f32x4*>(abuf + (p * 4 + rs) * LDSW + c4 * 4) = pre[p];
+    } else {
+#pragma unroll
+      for (int p = 0; p < NP16; ++p) {
+        f32x4 v = pre[p];
+        v.x = c + 0 < width ? v.x : 0.f; v.y = c + 1 < width ? v.y : 0.f;
+        v.z = c + 2 < width ? v.z : 0.f; v.w = c + 3 < width ? v.w : 0.f;
+        *reinterpret_cast<f32x4*>(abuf + (p * 4 + rs) * LDSW + c4 * 4) = v;
+      }
+    }
+    compiler_lds_barrier();
+  };
+  // accumulator tiles -> whole rows of dst ([rows, ld], columns < width), 64 columns at a time through the wave's tile
+  auto emit = [&](const f32x4 (&acc)[NTL], float* dst, int ld, int width, int row0) {
+#pragma unroll
+    for (int cc = 0; cc < NCH; ++cc) {
+      if (cc * KC < width) {
+        compiler_lds_barrier();
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+          if (4 * cc + cb < NTL) *reinterpret_cast<f32x4*>(abuf + i * LDSW + 16 * cb + 4 * g) = acc[4 * cc + cb < NTL ? 4 * cc + cb : 0];
+        compiler_lds_barrier();
+        store_staged_rows<NP16, false>(abuf, dst + cc * KC, ld, width - cc * KC < KC ? width - cc * KC : KC, row0, rows, c4, rs);
+      }
+    }
+    compiler_lds_barrier();
+  };
+
+  f32x4 wreg[NW];
+  wload(wreg, 0);
+  wstore(wreg);
+  __syncthreads();
+  auto prefetch_next_chunk = [&](int q) { wload(wreg, q + 1 < pl.num_wchunks ? q + 1 : 0); };
+  auto publish_next_chunk = [&]() {
+    __syncthreads();  // everyone is done reading the buffer
+    wstore(wreg);
+    __syncthreads();
+  };
+
+  // the row stream of a tile: the first Linear's staging steps, then the grad_out slabs; item k + 1 is requested while
+  // item k is being consumed, the next tile's first item while the last slab of this one is
+  int ids[GNC_MAX_SEGMENTS], ids_next[GNC_MAX_SEGMENTS];
+  int tile = blockIdx.x;
+#pragma unroll
+  for (int s = 0; s < GNC_MAX_SEGMENTS; ++s) {
+    ids[s] = s < d.num_segments ? load_idx(tile, s) : 0;
+    ids_next[s] = s < d.num_segments ? load_idx(tile + (int)gridDim.x, s) : 0;
+  }
+  auto id_of = [&](int s) {
+    int v = 0;
+#pragma unroll
+    for (int k = 0; k < GNC_MAX_SEGMENTS; ++k) v = k == s ? ids[k] : v;
+    return v;
+  };
+  auto load_step = [&](f32x4 (&pre)[NP16], int st, int tile_of) {
+    const gnc_mlp_segment_t& sg = d.seg[pl.step[st].seg];
+    load_rows(pre, sg.ptr, sg.ld, sg.index, sg.table_rows, pl.step[st].c0, id_of(pl.step[st].seg), tile_of);
+  };
+  f32x4 cur[NP16];
+  load_step(cur, 0, tile);
+  const int n_gslabs = (out_dim + KC - 1) / KC;
+
+  while (tile < num_tiles) {
+    const int row0 = (tile * W16 + wave) * R16;
+    const int ntile = tile + gridDim.x;
+    int q = 0;
+
+    // ------------------------------------------------------------------ forward recompute: first Linear
+    f32x4 hid[NTL];
+    init_bias16<NTL>(hid, pbuf, g);
+    for (int st = 0; st < pl.num_steps; ++st) {
+      const int s = pl.step[st].seg, c0 = pl.step[st].c0;
+      const int width = d.seg[s].width;
+      stage(cur, c0, width);
+      if (st + 1 < pl.num_steps) load_step(cur, st + 1, tile);
+      else load_rows(cur, b.grad_out, b.ld_grad_out, nullptr, 0, 0, 0, tile);  // first grad_out slab
+      if (pl.step[st].add) {
+        const int t0 = c0 >> 4;
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(abuf + i * LDSW + 16 * cb + 4 * g);
+#pragma unroll
+          for (int t = 0; t < NTL; ++t)
+            if (t == t0 + cb) hid[t] += v;
+        }
+      } else {
+        prefetch_next_chunk(q);
+        const int kc = width - c0 < KC ? width - c0 : KC;
+        mma16_chunk_from_lds<NTL>(hid, abuf, wbuf, (kc + 15) >> 4, i, g);
+        publish_next_chunk();
+        ++q;
+      }
+    }
+    unsigned mask[GNC_MAX_LINEAR - 1][MW];
+    relu_mask16<NTL>(hid, mask[0]);
+    emit(hid, b.act[0], d.out_dim[0], d.out_dim[0], row0);
+
+    // ------------------------------------------------------------------ hidden layers
+#pragma unroll
+    for (int l = 1; l < GNC_MAX_LINEAR - 1; ++l) {
+      if (l < L - 1) {
+        f32x4 nxt[NTL];
+        init_bias16<NTL>(nxt, pbuf + l * PSTRIDE, g);
+#define GNC_B16_FWD(C_, DST_, LAYER_)                                                \
+  if constexpr (C_ < NCH) {                                                          \
+    if (C_ * KC < d.in_dim[LAYER_]) {                                                \
+      prefetch_next_chunk(q);                                                        \
+      mma16_chunk_from_regs<NTL, NTL, C_>(DST_, hid, wbuf, d.in_dim[LAYER_], i, g);  \
+      publish_next_chunk();                                                          \
+      ++q;                                                                           \
+    }                                                                                \
+  }
+        GNC_B16_FWD(0, nxt, l) GNC_B16_FWD(1, nxt, l) GNC_B16_FWD(2, nxt, l) GNC_B16_FWD(3, nxt, l)
+        relu_mask16<NTL>(nxt, mask[l]);
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) hid[t] = nxt[t];
+        emit(hid, b.act[l], d.out_dim[l], d.out_dim[l], row0);
+      }
+    }
+
+    // ------------------------------------------------------------------ grad_out tile (slab by slab), LayerNorm backward
+    f32x4 gr[NTL];
+#pragma unroll
+    for (int cc = 0; cc < NCH; ++cc) {
+      if (cc < n_gslabs) {
+        stage(cur, cc * KC, out_dim);
+        if (cc + 1 < n_gslabs) {
+          load_rows(cur, b.grad_out, b.ld_grad_out, nullptr, 0, (cc + 1) * KC, 0, tile);
+        } else {  // the next tile's first staging step
+#pragma unroll
+          for (int k = 0; k < GNC_MAX_SEGMENTS; ++k) {
+            ids[k] = ids_next[k];
+            if (k < d.num_segments) ids_next[k] = load_idx(ntile + (int)gridDim.x, k);
+          }
+          load_step(cur, 0, ntile);
+        }
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+          if (4 * cc + cb < NTL) gr[4 * cc + cb < NTL ? 4 * cc + cb : 0] = *reinterpret_cast<const f32x4*>(abuf + i * LDSW + 16 * cb + 4 * g);
+        compiler_lds_barrier();
+      } else {
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+          if (4 * cc + cb < NTL) gr[4 * cc + cb < NTL ? 4 * cc + cb : 0] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    if (d.ln_gamma) {
+      f32x4 y[NTL];
+      init_bias16<NTL>(y, pbuf + (L - 1) * PSTRIDE, g);
+      GNC_B16_FWD(0, y, L - 1) GNC_B16_FWD(1, y, L - 1) GNC_B16_FWD(2, y, L - 1) GNC_B16_FWD(3, y, L - 1)
+      layer_norm_backward16<NTL>(y, gr, pbuf + L * PSTRIDE, out_dim, d.ln_eps, g);
+      emit(y, b.yhat, out_dim, out_dim, row0);  // normalised pre-affine output: d gamma = colsum(grad_out * y_hat)
+    } else {
+#pragma unroll
+      for (int t = 0; t < NTL; ++t) {
+        const int f = 16 * t + 4 * g;
+        gr[t].x = f + 0 < out_dim ? gr[t].x : 0.f; gr[t].y = f + 1 < out_dim ? gr[t].y : 0.f;
+        gr[t].z = f + 2 < out_dim ? gr[t].z : 0.f; gr[t].w = f + 3 < out_dim ? gr[t].w : 0.f;
+      }
+    }
+#undef GNC_B16_FWD
+    emit(gr, b.dz[L - 1], out_dim, out_dim, row0);
+
+    // ------------------------------------------------------------------ back through the Linear layers
+#define GNC_B16_BWD(C_, DST_, NTO_, LAYER_)                                          \
+  if constexpr (C_ < NCH) {                                                          \
+    if (C_ * KC < d.in_dim[LAYER_]) {                                                \
+      prefetch_next_chunk(q);                                                        \
+      mma16_transposed_chunk<NTL, NTO_, 4 * C_>(DST_, gr, wbuf, i, g);               \
+      publish_next_chunk();                                                          \
+      ++q;                                                                           \
+    }                                                                                \
+  }
+#pragma unroll
+    for (int l = GNC_MAX_LINEAR - 2; l >= 0; --l) {
+      if (l < L - 1) {
+        f32x4 da[NTL];
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) da[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        GNC_B16_BWD(0, da, NTL, l + 1) GNC_B16_BWD(1, da, NTL, l + 1) GNC_B16_BWD(2, da, NTL, l + 1) GNC_B16_BWD(3, da, NTL, l + 1)
+        apply_mask16<NTL>(da, mask[l]);
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) gr[t] = da[t];
+        emit(gr, b.dz[l], d.out_dim[l], d.out_dim[l], row0);
+      }
+    }
+#undef GNC_B16_BWD
+    if (b.dx) {  // one 64-column slab of dx per MATMUL step, in step order (= the order of the plan's last chunks)
+      for (int st = 0; st < pl.num_steps; ++st) {
+        if (pl.step[st].add) continue;
+        const int s = pl.step[st].seg, c0 = pl.step[st].c0;
+        f32x4 dxs[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dxs[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        prefetch_next_chunk(q);
+        mma16_transposed_chunk<NTL, 4, 0>(dxs, gr, wbuf, i, g);
+        publish_next_chunk();
+        ++q;
+        compiler_lds_barrier();
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) *reinterpret_cast<f32x4*>(abuf + i * LDSW + 16 * cb + 4 * g) = dxs[cb];
+        compiler_lds_barrier();
+        store_staged_rows<NP16, false>(abuf, b.dx + d.seg[s].wcol + c0, b.ld_dx, d.seg[s].width - c0 < KC ? d.seg[s].width - c0 : KC,
+                                       row0, rows, c4, rs);
+        compiler_lds_barrier();
+      }
+    }
+    tile = ntile;
+  }
+}
+
+bool al16b(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+bool make_plan(const gnc_mlp_desc_t& d, bool want_dx, BPlan16* pl) {
+  const int L = d.num_linear;
+  if (L < 2 || L > GNC_MAX_LINEAR - 1 || d.activation != GNC_ACT_RELU || d.rows < 1 || d.rows >= INT32_MAX - (1 << 22)) return false;
+  int wmax = 0;
+  for (int l = 0; l < L; ++l) {
+    if (d.out_dim[l] > wmax) wmax = d.out_dim[l];
+    if (l > 0 && d.in_dim[l] > wmax) wmax = d.in_dim[l];
+    if (ldw_of(d, l) % 4 != 0 || !al16b(d.weight[l])) return false;
+  }
+  if (wmax > 256) return false;
+  *pl = BPlan16{};
+  for (int pass = 0; pass < 2; ++pass)  // MATMUL segments first, then the additive ones
+    for (int s = 0; s < d.num_segments; ++s) {
+      const gnc_mlp_segment_t& sg = d.seg[s];
+      if (sg.ld % 4 != 0 || !al16b(sg.ptr)) return false;
+      if (sg.index && (sg.table_rows <= 0 || sg.table_rows * (int64_t)sg.ld * 4 > 0xffffffffll)) return false;
+      const bool add = sg.mode == GNC_SEG_ADD;
+      if ((pass == 1) != add) continue;
+      if (!add && sg.wcol % 4 != 0) return false;
+      for (int c0 = 0; c0 < sg.width; c0 += KC) {
+        if (pl->num_steps >= B16_MAX_STEPS) return false;
+        pl->step[pl->num_steps++] = {(short)s, (short)c0, (short)(add ? 1 : 0), 0};
+        if (!add) {
+          if (pl->num_wchunks >= B16_MAX_WCHUNKS) return false;
+          pl->wc[pl->num_wchunks++] = {(short)0, (short)(sg.wcol + c0), (short)(sg.wcol + sg.width), 0};
+        }
+      }
+    }
+  if (pl->num_wchunks == 0) return false;
+  const int mm_chunks = pl->num_wchunks;
+  auto push_layer = [&](int l) {
+    for (int c = 0; c * KC < d.in_dim[l]; ++c) {
+      if (pl->num_wchunks >= B16_MAX_WCHUNKS) return false;
+      pl->wc[pl->num_wchunks++] = {(short)l, (short)(c * KC), (short)d.in_dim[l], 0};
+    }
+    return true;
+  };
+  for (int l = 1; l < L - 1; ++l)
+    if (!push_layer(l)) return false;                     // forward, hidden layers
+  if (d.ln_gamma && !push_layer(L - 1)) return false;     // the last Linear only feeds the LayerNorm statistics
+  for (int l = L - 2; l >= 0; --l)
+    if (!push_layer(l + 1)) return false;                 // backward: W_{l+1}^T
+  if (want_dx)
+    for (int k = 0; k < mm_chunks; ++k) {                 // dx: the first Linear's chunks again, in step order
+      if (pl->num_wchunks >= B16_MAX_WCHUNKS) return false;
+      pl->wc[pl->num_wchunks] = pl->wc[k];
+      ++pl->num_wchunks;
+    }
+  return true;
+}
+
+}  // namespace
+
+bool gnc_mlp::bwd_stream16_supported(const gnc_mlp_desc_t& d, bool want_dx) {
+  BPlan16 pl;
+  return make_plan(d, want_dx, &pl);
+}
+
+int gnc_mlp::launch_bwd_stream16(const gnc_mlp_desc_t& d, const BwdArgs& b, hipStream_t stream) {
+  BPlan16 pl;
+  if (!make_plan(d, b.dx != nullptr, &pl)) {
+    gnc::set_error("mlp_backward_stream16: shape outside the kernel");
+    return GNC_ERR_UNSUPPORTED;
+  }
+  constexpr int NTL = 16;
+  const size_t smem = ((size_t)NTL * 16 * LDSW + (size_t)(d.num_linear + 2) * NTL * 16 + (size_t)W16 * R16 * LDSW) * sizeof(float);
+  static_assert(((size_t)16 * 16 * LDSW + (size_t)(GNC_MAX_LINEAR + 2) * 256 + (size_t)W16 * R16 * LDSW) * sizeof(float) <= 160 * 1024,
+                "backward16: LDS budget");
+  static bool attr_set = false;
+  if (!attr_set) {
+    int rc = gnc::check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_backward_stream16_kernel<NTL>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                            "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    if (rc) return rc;
+    attr_set = true;
+  }
+  const int64_t num_tiles = gnc::ceil_div(d.rows, (int64_t)W16 * R16);
+  const int64_t grid = num_tiles < gnc::num_cu() ? num_tiles : gnc::num_cu();
+  mlp_backward_stream16_kernel<NTL><<<dim3((unsigned)grid), dim3(NT16), smem, stream>>>(d, b, pl, (int)num_tiles);
+  return gnc::check_launch("mlp_backward_stream16_kernel");
+}

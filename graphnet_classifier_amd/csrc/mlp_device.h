@@ -692,6 +692,19 @@ struct SegView {  // wave-uniform view of one segment
 };
 
 
+// outputs of the K8 data kernels (mlp_backward.hip, mlp_backward16.hip), see gnc_mlp_bwd_desc_t
+struct BwdArgs {
+  const float* grad_out;
+  int ld_grad_out;
+  float* act[GNC_MAX_LINEAR];  // [rows, H] post-activation outputs of layers 0 .. L-2
+  float* dz[GNC_MAX_LINEAR];   // [rows, width_l] grad wrt the pre-activation of layer l (l = L-1: pre-LayerNorm)
+  float* dx;                   // nullable: [rows, in_dim0] grad wrt the MATMUL part of the input
+  int ld_dx;
+  float* yhat;                 // [rows, out_dim] normalised pre-affine output (only with LayerNorm)
+  int dx_add_grad_out;         // add grad_out rows to dx (the residual path of a segment that is also the residual)
+  float* ln_partial;           // nullable: [waves, 2 * out_dim] per-wave [colsum(grad_out) | colsum(grad_out * yhat)]
+};
+
 // smallest of {1,2,4,8} accumulator tiles (32 features each) covering `width`
 __host__ __device__ inline int ldw_of(const gnc_mlp_desc_t& d, int l) { return d.ld_weight[l] ? d.ld_weight[l] : d.in_dim[l]; }
 
@@ -711,5 +724,8 @@ int launch_stream(const gnc_mlp_desc_t& d, int T, bool narrow_out, hipStream_t s
                   bool probe_only = false);
 // widths 129..256 on v_mfma_f32_16x16x4_f32, 16 rows per wave (mlp_stream16.hip); same contract
 int launch_stream16(const gnc_mlp_desc_t& d, hipStream_t stream, bool* launched);
+// K8 data kernel for widths 129..256 on 16-row tiles (mlp_backward16.hip): shape query / launch
+bool bwd_stream16_supported(const gnc_mlp_desc_t& d, bool want_dx);
+int launch_bwd_stream16(const gnc_mlp_desc_t& d, const BwdArgs& b, hipStream_t stream);
 
 }  // namespace gnc_mlp

@@ -552,8 +552,8 @@ def mlp_backward(segments, weights, biases, ln, grad_out: torch.Tensor, rows: in
 
 
 def xty(a: torch.Tensor, b: torch.Tensor):
-    """(A^T B [M, K], column sums of A [M]) over the rows; A [rows, M], B [rows, K] fp32.  Blocks of
-    64 x 64 per launch; per-wave partials are summed in a fixed order (bitwise reproducible)."""
+    """(A^T B [M, K], column sums of A [M]) over the rows; A [rows, M], B [rows, K] fp32.  Blocks of up to
+    128 x 128 per launch; per-wave partials are summed in a fixed order (bitwise reproducible)."""
     lib = load_library()
     _require_cuda(a, b)
     a, b = _rowmajor(a), _rowmajor(b)
@@ -563,10 +563,10 @@ def xty(a: torch.Tensor, b: torch.Tensor):
     colsum = torch.empty(m, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         p = lib.gnc_xty_partials(rows)
-        for m0 in range(0, m, 64):
-            mm = min(64, m - m0)
-            for k0 in range(0, k, 64):
-                kk = min(64, k - k0)
+        for m0 in range(0, m, 128):
+            mm = min(128, m - m0)
+            for k0 in range(0, k, 128):
+                kk = min(128, k - k0)
                 part = torch.empty(p, mm * kk + mm, dtype=torch.float32, device=dev)
                 av, bv = a[:, m0:m0 + mm], b[:, k0:k0 + kk]
                 _check(_launch("xty", av, lambda: lib.gnc_xty_f32(av.data_ptr(), _ld(av), bv.data_ptr(), _ld(bv), rows, mm,
@@ -584,15 +584,19 @@ def colsum_pair(g: torch.Tensor, y: torch.Tensor):
     lib = load_library()
     g, y = _vector_rows(_rowmajor(g)), _vector_rows(_rowmajor(y))
     rows, width = g.shape
-    if width > 64:
-        return g.sum(0), (g * y).sum(0)  # wide LayerNorm: PyTorch-ROCm reduction
+    sg = torch.empty(width, dtype=torch.float32, device=g.device)
+    sgy = torch.empty(width, dtype=torch.float32, device=g.device)
     with torch.cuda.device(g.device):
         p = lib.gnc_xty_partials(rows)
-        part = torch.empty(p, 2 * width, dtype=torch.float32, device=g.device)
-        _check(lib.gnc_colsum_pair_f32(g.data_ptr(), _ld(g), y.data_ptr(), _ld(y), rows, width, part.data_ptr(), p,
-                                       _stream(g)), "gnc_colsum_pair_f32")
-    tot = part.sum(dim=0)
-    return tot[:width], tot[width:]
+        for c0 in range(0, width, 64):  # 64-column slabs (a wide LayerNorm is a few launches over column slices)
+            w = min(64, width - c0)
+            gs, ys = g[:, c0:c0 + w], y[:, c0:c0 + w]
+            part = torch.empty(p, 2 * w, dtype=torch.float32, device=g.device)
+            _check(lib.gnc_colsum_pair_f32(gs.data_ptr(), _ld(g), ys.data_ptr(), _ld(y), rows, w, part.data_ptr(), p,
+                                           _stream(g)), "gnc_colsum_pair_f32")
+            tot = part.sum(dim=0)
+            sg[c0:c0 + w], sgy[c0:c0 + w] = tot[:w], tot[w:]
+    return sg, sgy
 
 
 # --------------------------------------------------------------------------- fused Adam

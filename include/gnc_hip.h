@@ -222,11 +222,13 @@ int gnc_agg_fixup_f32(const float* src, int64_t ld_src, const int32_t* rowptr, c
  *   db_l = column sums of dz[l] -> gnc_xty_f32.
  *   Supported: ReLU, 2 <= num_linear <= 7, tables 16-B aligned with ld % 4 == 0; widths <= 64 with every
  *   segment <= 64 columns and MATMUL segments listed before 0 or 2 ADD segments run with LDS-resident
- *   weights, other shapes up to width 128 stream the weights (also needs 16-B aligned weights);
+ *   weights, other shapes up to width 128 stream the weights on 32-row tiles, widths 129..256 on 16-row tiles
+ *   (v_mfma_f32_16x16x4_f32; both streaming forms need 16-B aligned weights, the 16-row one stated gather tables);
  *   gnc_mlp_backward_supported() answers from the shape fields alone.
  *
  * gnc_xty_f32: partial[w] = [ A^T B (M x K, row-major) | column sums of A (M) ] over the rows wave w
- *   streamed; sum the num_partials = gnc_xty_partials(rows) rows (fixed order => reproducible).  M, K <= 64.
+ *   streamed; sum the num_partials = gnc_xty_partials(rows) rows (fixed order => reproducible).  M, K <= 128
+ *   (a 256 x 256 weight gradient is four launches over [rows, 128] column slabs).
  * gnc_colsum_pair_f32: partial[w] = [ colsum(G) (width) | colsum(G * Y) (width) ], same partial count.
  */
 typedef struct gnc_mlp_bwd_desc {

@@ -403,7 +403,8 @@ def test_mlp_rejects_unsupported(native):
 
 
 # ------------------------------------------------------------------ K8 backward kernels
-@pytest.mark.parametrize("m,k", [(64, 64), (64, 3), (16, 40), (128, 64), (64, 192)])
+@pytest.mark.parametrize("m,k", [(64, 64), (64, 3), (16, 40), (128, 64), (64, 192), (128, 128), (256, 256), (130, 70), (96, 256),
+                                 (256, 4)])
 def test_xty_matches_matmul(native, m, k):
     rng = np.random.default_rng(m * 7 + k)
     rows = 4099
@@ -418,10 +419,11 @@ def test_xty_matches_matmul(native, m, k):
     assert torch.equal(c, c2)  # fixed summation order
 
 
-def test_colsum_pair(native):
+@pytest.mark.parametrize("width", [64, 40, 128, 200, 256])
+def test_colsum_pair(native, width):
     rng = np.random.default_rng(9)
-    g = torch.from_numpy(rng.standard_normal((5003, 64)).astype(np.float32))
-    y = torch.from_numpy(rng.standard_normal((5003, 64)).astype(np.float32))
+    g = torch.from_numpy(rng.standard_normal((5003, width)).astype(np.float32))
+    y = torch.from_numpy(rng.standard_normal((5003, width)).astype(np.float32))
     sg, sgy = native.colsum_pair(g.to(DEV), y.to(DEV))
     assert max_abs(sg.cpu(), g.double().sum(0).float()) < 1e-3
     assert max_abs(sgy.cpu(), (g.double() * y.double()).sum(0).float()) < 1e-3
@@ -455,6 +457,13 @@ def _torch_mlp(sd, x_cat, residual=None):
     ((4,), 128, 128, 2, True, False),
     ((128,), 128, 1, 2, False, False),
     ((96, 40), 100, 72, 3, True, False),
+    ((256,), 256, 256, 2, True, False),       # widths 129..256: 16-row streamed-weights variant (mlp_backward16.hip)
+    ((256, 256), 256, 256, 2, True, True),
+    ((256, 256, 256), 256, 256, 2, True, True),
+    ((4,), 256, 256, 2, True, False),
+    ((256,), 256, 1, 2, False, False),
+    ((200, 72), 136, 160, 3, True, False),
+    ((64,), 192, 64, 1, True, False),
 ])
 @pytest.mark.parametrize("fused", [False, True])
 def test_mlp_backward_kernel_matches_autograd(native, in_dims, hidden, out_dim, hl, ln, res, fused):

@@ -266,7 +266,7 @@ def test_hip_backward_agrees_with_torch_recompute_backward(G, monkeypatch):
     batch = S.superpixel_like_graphs(6, seed=11)
     x, pos, ei = batch.x.to(DEV), batch.pos.to(DEV), batch.edge_index.to(DEV)
     w = torch.randn(batch.num_nodes, 1, device=DEV)
-    for width in (64, 128):  # resident-weights and streamed-weights backward kernels
+    for width in (64, 128, 256):  # resident-weights, streamed-weights (32-row) and 16-row streamed-weights backward kernels
         torch.manual_seed(5)
         m = G.GraphNet(**S.graphnet_kwargs(width, 2))
         grads = {}
