@@ -440,8 +440,12 @@ __global__ __launch_bounds__(FNT) void mlp_backward_fused_kernel(const gnc_mlp_d
     compiler_lds_barrier();
   };
 
-  // gather ids travel one tile ahead (two registers): the gathers of a tile then cost one memory round trip, not two
-  int ids_nxt[2] = {0, 0};
+  // Load schedule.  Everything a tile reads from memory - its e rows, its grad_out rows, the two gathered projection
+  // rows - is requested during the PREVIOUS tile's backward phases, at the points where the accumulator sets of the
+  // chain have died and registers are free (after layer 2: e and grad_out; after layer 1: the gathers), and is
+  // parked in the wave's LDS tiles the moment the tile starts: no load latency is exposed inside a tile, and no
+  // row piece is kept in registers across the forward recompute.  Gather ids travel two tiles ahead.
+  int ids_nxt[2] = {0, 0}, ids_cur[2] = {0, 0};
   auto load_ids = [&](int wt_) {
     if constexpr (NADD > 0) {
       int r = wt_ * RPW + (lane & 31);
@@ -450,15 +454,8 @@ __global__ __launch_bounds__(FNT) void mlp_backward_fused_kernel(const gnc_mlp_d
       ids_nxt[1] = d.seg[2].index[r];
     }
   };
-  load_ids((int)blockIdx.x * FWAVES + wave);
-  for (int wt = (int)blockIdx.x * FWAVES + wave; wt < num_wtiles; wt += total_waves) {
-    const int row0 = wt * RPW;
-    // ---------------------------------------------------------------- the tile's rows
-    f32x4 pe[NP], pg[NP], pa[NADD ? NP : 1], pb[NADD ? NP : 1];
-    load_tile_rows(pe, s0.ptr, s0.ld, row0, rows, e_off);
-    load_tile_rows(pg, b.grad_out, b.ld_grad_out, row0, rows, g_off);
+  auto gather_rows_of = [&](f32x4 (&pa)[NADD ? NP : 1], f32x4 (&pb)[NADD ? NP : 1]) {
     if constexpr (NADD > 0) {
-      const int ids_cur[2] = {ids_nxt[0], ids_nxt[1]};
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const gnc_mlp_segment_t& sg = d.seg[1 + k];
@@ -472,19 +469,34 @@ __global__ __launch_bounds__(FNT) void mlp_backward_fused_kernel(const gnc_mlp_d
           if (k == 0) pa[p] = v; else pb[p] = v;
         }
       }
-      load_ids(wt + total_waves);
     }
-    // ---------------------------------------------------------------- forward recompute
+  };
+  const int wt0 = (int)blockIdx.x * FWAVES + wave;
+  f32x4 pe[NP], pg[NP], pa[NADD ? NP : 1], pb[NADD ? NP : 1];
+  load_ids(wt0);
+  ids_cur[0] = ids_nxt[0]; ids_cur[1] = ids_nxt[1];
+  load_ids(wt0 + total_waves);
+  load_tile_rows(pe, s0.ptr, s0.ld, wt0 * RPW, rows, e_off);   // past-the-end tiles read zeros
+  load_tile_rows(pg, b.grad_out, b.ld_grad_out, wt0 * RPW, rows, g_off);
+  gather_rows_of(pa, pb);
+  for (int wt = wt0; wt < num_wtiles; wt += total_waves) {
+    const int row0 = wt * RPW;
+    const int nrow0 = (wt + total_waves) * RPW;  // may lie past the end: windows return zeros, ids are clamped
+    // ---------------------------------------------------------------- park the tile's rows
     to_tile(te, pe, s0.width);
-    f32x16 a0[HT];
-    init_bias<HT>(a0, pbuf, h);
-    mma_chunk_from_lds<HT>(a0, te, wres, (s0.width + 7) >> 3, i, h);
+    to_tile(tb, pg, out_dim);
     if constexpr (NADD > 0) {
 #pragma unroll
       for (int p = 0; p < NP; ++p) pa[p] += pb[p];
       to_tile(ta, pa, d.seg[1].width);
-      add_tile_from_lds<HT>(a0, ta, i, h);
+      ids_cur[0] = ids_nxt[0]; ids_cur[1] = ids_nxt[1];
+      load_ids(wt + 2 * total_waves);
     }
+    // ---------------------------------------------------------------- forward recompute
+    f32x16 a0[HT];
+    init_bias<HT>(a0, pbuf, h);
+    mma_chunk_from_lds<HT>(a0, te, wres, (s0.width + 7) >> 3, i, h);
+    if constexpr (NADD > 0) add_tile_from_lds<HT>(a0, ta, i, h);
     relu_tiles<HT>(a0);
     f32x16 a1[HT];
     init_bias<HT>(a1, pbuf + PSTRIDE, h);
@@ -492,19 +504,19 @@ __global__ __launch_bounds__(FNT) void mlp_backward_fused_kernel(const gnc_mlp_d
     relu_tiles<HT>(a1);
     // ---------------------------------------------------------------- grad of the pre-LayerNorm output
     f32x16 g[HT];
-    to_tile(tb, pg, out_dim);
     tile_from_lds<HT>(g, tb, i, h);
     if (d.ln_gamma) {
       f32x16 y[HT];
       init_bias<HT>(y, pbuf + 2 * PSTRIDE, h);
       mma_chunk_from_regs<HT, HT>(y, a1, wres + 2 * CH, 0, d.in_dim[2], i, h);
       layer_norm_backward_tiles<HT>(y, g, pbuf + L * PSTRIDE, out_dim, d.ln_eps, h);
-      acc_to_tile(tb, y);  // y_hat as whole rows: the LayerNorm parameter sums (grad_out's pieces are still in pg)
+      acc_to_tile(ta, y);  // y_hat as whole rows next to grad_out's rows (still in tb): the LayerNorm parameter sums
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
-        const f32x4 yh = *reinterpret_cast<const f32x4*>(tb + (p * 4 + rs) * LDSW + c4 * 4);
-        sum_g += pg[p];
-        sum_gy = __builtin_elementwise_fma(pg[p], yh, sum_gy);
+        const f32x4 yh = *reinterpret_cast<const f32x4*>(ta + (p * 4 + rs) * LDSW + c4 * 4);
+        const f32x4 gp = *reinterpret_cast<const f32x4*>(tb + (p * 4 + rs) * LDSW + c4 * 4);
+        sum_g += gp;
+        sum_gy = __builtin_elementwise_fma(gp, yh, sum_gy);
       }
     } else {
 #pragma unroll
@@ -523,6 +535,9 @@ __global__ __launch_bounds__(FNT) void mlp_backward_fused_kernel(const gnc_mlp_d
 #pragma unroll
       for (int t = 0; t < HT; ++t) g[t] = da[t];
     }
+    // a1 is dead: the next tile's e and grad_out rows are requested here and land under layers 1 and 0
+    load_tile_rows(pe, s0.ptr, s0.ld, nrow0, rows, e_off);
+    load_tile_rows(pg, b.grad_out, b.ld_grad_out, nrow0, rows, g_off);
     // ---------------------------------------------------------------- layer 1
     acc_to_tile(tb, g);
     acc_to_tile(ta, a0);
@@ -534,17 +549,37 @@ __global__ __launch_bounds__(FNT) void mlp_backward_fused_kernel(const gnc_mlp_d
 #pragma unroll
       for (int t = 0; t < HT; ++t) g[t] = da[t];
     }
+    // a0 is dead: the next tile's gathered rows, and this tile's grad_out rows again for the residual path of dx
+    gather_rows_of(pa, pb);
+    f32x4 gres[NP];
+    if (b.dx && b.dx_add_grad_out) load_tile_rows(gres, b.grad_out, b.ld_grad_out, row0, rows, g_off);
     // ---------------------------------------------------------------- layer 0: dW0 += dz0^T e, dz0 out, dx
     acc_to_tile(tb, g);
     xty_tile(dW0, cs0, tb, te, i, h);
-    asm volatile("" ::"v"(ids_nxt[0]), "v"(ids_nxt[1]));  // collected before the asm stores join the queue
-    if (b.dz[0]) store_staged_rows(tb, b.dz[0], d.out_dim[0], d.out_dim[0], row0, rows, c4, rs);
+    f32x16 dxs[HT];
     if (b.dx) {
-      f32x16 dxs[HT];
       mma_transposed_from_regs<HT, HT, true>(dxs, g, wres, i, h);
       acc_to_tile(ta, dxs);
-      store_staged_rows(ta, b.dx + s0.wcol, b.ld_dx, s0.width, row0, rows, c4, rs, b.dx_add_grad_out ? b.grad_out : nullptr,
-                        b.ld_grad_out);
+    }
+    // everything requested above is collected before the asm stores join the memory queue
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      asm volatile("" ::"v"(pe[p]), "v"(pg[p]));
+      if constexpr (NADD > 0) asm volatile("" ::"v"(pa[p]), "v"(pb[p]));
+    }
+    asm volatile("" ::"v"(ids_nxt[0]), "v"(ids_nxt[1]));
+    if (b.dz[0]) store_staged_rows(tb, b.dz[0], d.out_dim[0], d.out_dim[0], row0, rows, c4, rs);
+    if (b.dx) {
+      if (b.dx_add_grad_out) {
+        compiler_lds_barrier();
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          float* q = ta + (p * 4 + rs) * LDSW + c4 * 4;
+          *reinterpret_cast<f32x4*>(q) = *reinterpret_cast<const f32x4*>(q) + gres[p];
+        }
+        compiler_lds_barrier();
+      }
+      store_staged_rows(ta, b.dx + s0.wcol, b.ld_dx, s0.width, row0, rows, c4, rs);
     }
     compiler_lds_barrier();
   }

@@ -509,3 +509,43 @@ def test_mlp_backward_kernel_matches_autograd(native, in_dims, hidden, out_dim, 
         dbeta, dgamma = r["ln_sums"] if r["ln_sums"] is not None else native.colsum_pair(gout.to(DEV), r["yhat"])
         assert float((dgamma.cpu().double() - sd64[lnk[0]].grad).abs().max()) < 1e-3
         assert float((dbeta.cpu().double() - sd64[lnk[0].replace("weight", "bias")].grad).abs().max()) < 1e-3
+
+
+@pytest.mark.parametrize("d", [64, 128, 256])
+def test_mlp_backward_wsplit_shape_matches_autograd(native, d):
+    """The W-split edge-processor shape in the K8 data kernels of every width class (weights-resident, 32-row streamed,
+    16-row streamed): two GATHERED additive segments + the row-ordered e table.  dz_0 (the gradient of both gathered
+    projections), dx (gradient through W_e, residual excluded) and the weight gradients against float64 autograd."""
+    rng = np.random.default_rng(d + 5)
+    n, e = 301, 2111
+    sd = _mlp_sd(rng, d, d, d, 2, True)   # first Linear = W_e (the e columns of W0); the projections arrive pre-multiplied
+    ps = torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32))
+    pd_ = torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32))
+    ea = torch.from_numpy(rng.standard_normal((e, d)).astype(np.float32))
+    src = torch.from_numpy(rng.integers(0, n, size=e).astype(np.int32))
+    dst = torch.from_numpy(np.sort(rng.integers(0, n, size=e)).astype(np.int32))
+    gout = torch.from_numpy(rng.standard_normal((e, d)).astype(np.float32))
+    sd64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    ps64, pd64, e64 = (t_.double().requires_grad_(True) for t_ in (ps, pd_, ea))
+    z0 = torch.nn.functional.linear(e64, sd64["m.model.0.weight"], sd64["m.model.0.bias"]) + ps64[src.long()] + pd64[dst.long()]
+    z0.retain_grad()
+    h = torch.relu(z0)
+    h = torch.relu(torch.nn.functional.linear(h, sd64["m.model.2.weight"], sd64["m.model.2.bias"]))
+    h = torch.nn.functional.linear(h, sd64["m.model.4.weight"], sd64["m.model.4.bias"])
+    h = torch.nn.functional.layer_norm(h, (d,), sd64["m.model.5.weight"], sd64["m.model.5.bias"], 1e-5) + e64
+    h.backward(gout.double())
+    ws = [sd[f"m.model.{i}.weight"].to(DEV) for i in (0, 2, 4)]
+    bs = [sd[f"m.model.{i}.bias"].to(DEV) for i in (0, 2, 4)]
+    ln = (sd["m.model.5.weight"].to(DEV), sd["m.model.5.bias"].to(DEV), 1e-5)
+    segs = [(ps.to(DEV), src.to(DEV)), (pd_.to(DEV), dst.to(DEV)), (ea.to(DEV), None)]
+    modes = [native.SEG_ADD, native.SEG_ADD, native.SEG_MATMUL]
+    assert native.mlp_backward_supported(segs, ws, bs, ln, "ReLU", ea.to(DEV), e, modes)
+    for fused in (False, True):
+        r = native.mlp_backward(segs, ws, bs, ln, gout.to(DEV), rows=e, modes=modes, need_dx=True, residual=ea.to(DEV), fused=fused)
+        assert max_abs(r["dz"][0].cpu(), z0.grad.float()) < 2e-5
+        dx_ref = e64.grad - (0 if r["residual_folded"] else gout.double())
+        assert max_abs(r["dx"].cpu(), dx_ref.float()) < 2e-5
+        if "dw" in r:
+            for li, k in enumerate(("m.model.0.weight", "m.model.2.weight", "m.model.4.weight")):
+                gw = sd64[k].grad
+                assert float((r["dw"][li].cpu().double() - gw).abs().max()) < 1e-4 * max(1.0, float(gw.abs().max())), (k, fused)
