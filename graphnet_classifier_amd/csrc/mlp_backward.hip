@@ -350,6 +350,85 @@ struct FusedOut {
   int M[3], K[3];
 };
 
+// The weight-gradient accumulators of the fused kernel live in AccVGPRs for the whole life of the wave and are touched
+// by nothing but these MFMAs, issued from inline asm with the accumulator pinned to the "a" register class.  Reason: a
+// kernel that needs more than 256 registers makes hipcc put EVERY MFMA result into AccVGPRs, and the chain's working
+// sets (which the vector unit post-processes: ReLU, masks, LayerNorm) then shuttle through v_accvgpr_read / _write -
+// ~1,100 static moves in the tile loop, each a vector-unit slot that fp32 MFMA time does not hide on gfx950.  With the
+// 192 accumulator registers out of the compiler's sight the rest of the kernel fits the 256 architectural VGPRs.
+// Hazards the compiler no longer tracks for these instructions: a dependent MFMA on the same accumulator needs 2 wait
+// states (the four accumulators of a step rotate, so 3 other MFMAs sit in between; `volatile` keeps that order), and
+// the accumulators are read by VALU only after the tile loop, behind an explicit s_nop block (agpr_mfma_fence).
+__device__ __forceinline__ void mfma_agpr(f32x16& acc, float a, float b) {
+  asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void agpr_mfma_fence() { asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory"); }
+
+// ... and because hipcc selects the AccVGPR form for every MFMA *builtin* of a function that owns AccVGPRs at all, the
+// chain's MFMAs of the fused kernel are issued from inline asm too, in VGPR form ("v" class): results land where the
+// vector unit reads them.  What the hazard recognizer would have done for them is done by hand:
+//   * XDL (16-pass) result -> VALU / LDS / VMEM read of it: 18 wait states.  Every chain ends in chain_fence(), an
+//     s_nop block that also takes the accumulators as in/out operands, so no consumer can be scheduled above it;
+//   * a dependent MFMA on the same accumulator (SrcC == vDst, same opcode) may follow back to back (hipcc emits that
+//     itself for the builtin form);
+//   * operands are VALU or LDS results: no hazard beyond the lgkmcnt wait the compiler still places, since they are
+//     ordinary asm inputs.
+__device__ __forceinline__ void mfma_vgpr(f32x16& acc, float a, float b) {
+  asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_vgpr_from_zero(f32x16& acc, float a, float b) {
+  asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void chain_fence(f32x16 (&acc)[2]) {
+  asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0]), "+v"(acc[1]));
+}
+// asm-issued counterparts of mma_chunk_from_lds / mma_chunk_from_regs (mlp_device.h) and mma_transposed_from_regs for
+// two accumulator tiles (widths <= 64)
+__device__ __forceinline__ void fmma_chunk_from_lds(f32x16 (&acc)[2], const float* abuf, const float* wbuf, int kc8, int i, int h) {
+#pragma unroll 2
+  for (int g = 0; g < kc8; ++g) {
+    const f32x4 b = *reinterpret_cast<const f32x4*>(abuf + i * LDSW + 8 * g + 4 * h);
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(wbuf + i * LDSW + 8 * g + 4 * h);
+    const f32x4 a1 = *reinterpret_cast<const f32x4*>(wbuf + (32 + i) * LDSW + 8 * g + 4 * h);
+    mfma_vgpr(acc[0], a0.x, b.x); mfma_vgpr(acc[1], a1.x, b.x);
+    mfma_vgpr(acc[0], a0.y, b.y); mfma_vgpr(acc[1], a1.y, b.y);
+    mfma_vgpr(acc[0], a0.z, b.z); mfma_vgpr(acc[1], a1.z, b.z);
+    mfma_vgpr(acc[0], a0.w, b.w); mfma_vgpr(acc[1], a1.w, b.w);
+  }
+}
+__device__ __forceinline__ void fmma_chunk_from_regs(f32x16 (&dst)[2], const f32x16 (&src)[2], const float* wbuf, int in_dim, int i,
+                                                     int h) {
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    if (g * 8 < in_dim) {
+      const int ts = g >> 2, q = g & 3;
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(wbuf + i * LDSW + 8 * g + 4 * h);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(wbuf + (32 + i) * LDSW + 8 * g + 4 * h);
+      mfma_vgpr(dst[0], a0.x, src[ts][4 * q + 0]); mfma_vgpr(dst[1], a1.x, src[ts][4 * q + 0]);
+      mfma_vgpr(dst[0], a0.y, src[ts][4 * q + 1]); mfma_vgpr(dst[1], a1.y, src[ts][4 * q + 1]);
+      mfma_vgpr(dst[0], a0.z, src[ts][4 * q + 2]); mfma_vgpr(dst[1], a1.z, src[ts][4 * q + 2]);
+      mfma_vgpr(dst[0], a0.w, src[ts][4 * q + 3]); mfma_vgpr(dst[1], a1.w, src[ts][4 * q + 3]);
+    }
+  }
+}
+// dst = W^T-tile * src (see mma_transposed_from_regs): the first MFMA of each output tile starts from the constant 0
+__device__ __forceinline__ void fmma_transposed_from_regs(f32x16 (&dst)[2], const f32x16 (&src)[2], const float* wbuf, int i, int h) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const float w0 = wbuf[n * LDSW + i], w1 = wbuf[n * LDSW + 32 + i];
+      if (t == 0 && r == 0) {
+        mfma_vgpr_from_zero(dst[0], w0, src[t][r]);
+        mfma_vgpr_from_zero(dst[1], w1, src[t][r]);
+      } else {
+        mfma_vgpr(dst[0], w0, src[t][r]);
+        mfma_vgpr(dst[1], w1, src[t][r]);
+      }
+    }
+}
+
 // acc[a][c] += sum over the tile's 32 rows of tm[row][32a + .] (x) tk[row][32c + .]; csum[a] += column sums of tm
 __device__ __forceinline__ void xty_tile(f32x16 (&acc)[2][2], float (&csum)[2], const float* tm, const float* tk, int i, int h) {
 #pragma unroll 4
@@ -365,7 +444,7 @@ __device__ __forceinline__ void xty_tile(f32x16 (&acc)[2][2], float (&csum)[2], 
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int c = 0; c < 2; ++c) acc[a][c] = mfma(av[a], bv[c], acc[a][c]);
+      for (int c = 0; c < 2; ++c) mfma_agpr(acc[a][c], av[a], bv[c]);
   }
 }
 
@@ -423,14 +502,17 @@ __global__ __launch_bounds__(FNT) void mlp_backward_fused_kernel(const gnc_mlp_d
   auto to_tile = [&](float* t, const f32x4 (&pre)[NP], int width) {  // whole-row pieces -> LDS tile, zero beyond `width`
     compiler_lds_barrier();
     const int c = c4 * 4;
+    if (width >= KC) {  // wave-uniform: the full-width case carries no masks
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      f32x4 v = pre[p];
-      if (width < KC) {
+      for (int p = 0; p < NP; ++p) *reinterpret_cast<f32x4*>(t + (p * 4 + rs) * LDSW + c) = pre[p];
+    } else {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        f32x4 v = pre[p];
         v.x = c + 0 < width ? v.x : 0.f; v.y = c + 1 < width ? v.y : 0.f;
         v.z = c + 2 < width ? v.z : 0.f; v.w = c + 3 < width ? v.w : 0.f;
+        *reinterpret_cast<f32x4*>(t + (p * 4 + rs) * LDSW + c) = v;
       }
-      *reinterpret_cast<f32x4*>(t + (p * 4 + rs) * LDSW + c) = v;
     }
     compiler_lds_barrier();
   };
@@ -443,8 +525,9 @@ __global__ __launch_bounds__(FNT) void mlp_backward_fused_kernel(const gnc_mlp_d
   // Load schedule.  Everything a tile reads from memory - its e rows, its grad_out rows, the two gathered projection
   // rows - is requested during the PREVIOUS tile's backward phases, at the points where the accumulator sets of the
   // chain have died and registers are free (after layer 2: e and grad_out; after layer 1: the gathers), and is
-  // parked in the wave's LDS tiles the moment the tile starts: no load latency is exposed inside a tile, and no
-  // row piece is kept in registers across the forward recompute.  Gather ids travel two tiles ahead.
+  // parked in the wave's LDS tiles at the END of that tile: no load latency is exposed inside a tile and no row
+  // piece is carried in registers across the loop's back edge or the forward recompute.  Gather ids travel two
+  // tiles ahead.
   int ids_nxt[2] = {0, 0}, ids_cur[2] = {0, 0};
   auto load_ids = [&](int wt_) {
     if constexpr (NADD > 0) {
@@ -479,28 +562,35 @@ __global__ __launch_bounds__(FNT) void mlp_backward_fused_kernel(const gnc_mlp_d
   load_tile_rows(pe, s0.ptr, s0.ld, wt0 * RPW, rows, e_off);   // past-the-end tiles read zeros
   load_tile_rows(pg, b.grad_out, b.ld_grad_out, wt0 * RPW, rows, g_off);
   gather_rows_of(pa, pb);
-  for (int wt = wt0; wt < num_wtiles; wt += total_waves) {
-    const int row0 = wt * RPW;
-    const int nrow0 = (wt + total_waves) * RPW;  // may lie past the end: windows return zeros, ids are clamped
-    // ---------------------------------------------------------------- park the tile's rows
+  // park a tile's rows in the wave's LDS tiles: e -> te, grad_out -> tb, the sum of the gathered projections -> ta
+  auto park = [&]() {
     to_tile(te, pe, s0.width);
     to_tile(tb, pg, out_dim);
     if constexpr (NADD > 0) {
 #pragma unroll
       for (int p = 0; p < NP; ++p) pa[p] += pb[p];
       to_tile(ta, pa, d.seg[1].width);
+    }
+  };
+  park();
+  for (int wt = wt0; wt < num_wtiles; wt += total_waves) {
+    const int row0 = wt * RPW;
+    const int nrow0 = (wt + total_waves) * RPW;  // may lie past the end: windows return zeros, ids are clamped
+    if constexpr (NADD > 0) {
       ids_cur[0] = ids_nxt[0]; ids_cur[1] = ids_nxt[1];
       load_ids(wt + 2 * total_waves);
     }
     // ---------------------------------------------------------------- forward recompute
     f32x16 a0[HT];
     init_bias<HT>(a0, pbuf, h);
-    mma_chunk_from_lds<HT>(a0, te, wres, (s0.width + 7) >> 3, i, h);
+    fmma_chunk_from_lds(a0, te, wres, (s0.width + 7) >> 3, i, h);
+    chain_fence(a0);
     if constexpr (NADD > 0) add_tile_from_lds<HT>(a0, ta, i, h);
     relu_tiles<HT>(a0);
     f32x16 a1[HT];
     init_bias<HT>(a1, pbuf + PSTRIDE, h);
-    mma_chunk_from_regs<HT, HT>(a1, a0, wres + CH, 0, d.in_dim[1], i, h);
+    fmma_chunk_from_regs(a1, a0, wres + CH, d.in_dim[1], i, h);
+    chain_fence(a1);
     relu_tiles<HT>(a1);
     // ---------------------------------------------------------------- grad of the pre-LayerNorm output
     f32x16 g[HT];
@@ -508,7 +598,8 @@ __global__ __launch_bounds__(FNT) void mlp_backward_fused_kernel(const gnc_mlp_d
     if (d.ln_gamma) {
       f32x16 y[HT];
       init_bias<HT>(y, pbuf + 2 * PSTRIDE, h);
-      mma_chunk_from_regs<HT, HT>(y, a1, wres + 2 * CH, 0, d.in_dim[2], i, h);
+      fmma_chunk_from_regs(y, a1, wres + 2 * CH, d.in_dim[2], i, h);
+      chain_fence(y);
       layer_norm_backward_tiles<HT>(y, g, pbuf + L * PSTRIDE, out_dim, d.ln_eps, h);
       acc_to_tile(ta, y);  // y_hat as whole rows next to grad_out's rows (still in tb): the LayerNorm parameter sums
 #pragma unroll
@@ -530,7 +621,8 @@ __global__ __launch_bounds__(FNT) void mlp_backward_fused_kernel(const gnc_mlp_d
     xty_tile(dW2, cs2, tb, ta, i, h);
     {
       f32x16 da[HT];
-      mma_transposed_from_regs<HT, HT, true>(da, g, wres + 2 * CH, i, h);
+      fmma_transposed_from_regs(da, g, wres + 2 * CH, i, h);
+      chain_fence(da);
       mask_by_positive<HT>(da, a1);
 #pragma unroll
       for (int t = 0; t < HT; ++t) g[t] = da[t];
@@ -544,7 +636,8 @@ __global__ __launch_bounds__(FNT) void mlp_backward_fused_kernel(const gnc_mlp_d
     xty_tile(dW1, cs1, tb, ta, i, h);
     {
       f32x16 da[HT];
-      mma_transposed_from_regs<HT, HT, true>(da, g, wres + CH, i, h);
+      fmma_transposed_from_regs(da, g, wres + CH, i, h);
+      chain_fence(da);
       mask_by_positive<HT>(da, a0);
 #pragma unroll
       for (int t = 0; t < HT; ++t) g[t] = da[t];
@@ -558,7 +651,8 @@ __global__ __launch_bounds__(FNT) void mlp_backward_fused_kernel(const gnc_mlp_d
     xty_tile(dW0, cs0, tb, te, i, h);
     f32x16 dxs[HT];
     if (b.dx) {
-      mma_transposed_from_regs<HT, HT, true>(dxs, g, wres, i, h);
+      fmma_transposed_from_regs(dxs, g, wres, i, h);
+      chain_fence(dxs);
       acc_to_tile(ta, dxs);
     }
     // everything requested above is collected before the asm stores join the memory queue
@@ -582,9 +676,11 @@ __global__ __launch_bounds__(FNT) void mlp_backward_fused_kernel(const gnc_mlp_d
       store_staged_rows(ta, b.dx + s0.wcol, b.ld_dx, s0.width, row0, rows, c4, rs);
     }
     compiler_lds_barrier();
+    park();  // the next tile's rows (requested above, long landed) into the tiles this one has finished with
   }
 
   // ------------------------------------------------------------------ one row of partials per wave and layer
+  agpr_mfma_fence();  // the last asm-issued MFMAs have written their accumulators before anything reads them
   const int gw = (int)blockIdx.x * FWAVES + wave;
   auto write_partial = [&](int l, const f32x16 (&acc)[2][2], const float (&cs)[2]) {
     const int M = fo.M[l], K = fo.K[l];
