@@ -22,6 +22,28 @@
 
 using namespace gnc_mlp;
 
+// Phase probe of the fused kernel (`make probe_bwd`): per-wave shader-clock cycles (s_memtime) per phase of the tile loop,
+// read back by tools/profile_bwd.py.  Off in the shipped library.
+#ifdef GNC_PHASE_PROBE
+__device__ unsigned long long gnc_phase_probe_bwd[4096 * 12];
+extern "C" int gnc_phase_probe_bwd_read(void* dst, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(gnc_phase_probe_bwd), bytes);
+}
+#define BPROBE_BEGIN() unsigned long long pr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pr_tp, pr_tn; \
+  const unsigned long long pr_c0 = __builtin_readcyclecounter(), pr_w0 = wall_clock64()
+#define BPROBE_TILE() pr_tp = __builtin_readcyclecounter()
+#define BPROBE(k) do { pr_tn = __builtin_readcyclecounter(); pr_acc[k] += pr_tn - pr_tp; pr_tp = pr_tn; } while (0)
+#define BPROBE_END() do { if ((threadIdx.x & 63) == 0) {                                                        \
+    unsigned long long* o = gnc_phase_probe_bwd + (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 12;  \
+    for (int k = 0; k < 8; ++k) o[k] = pr_acc[k];                                                               \
+    o[8] = __builtin_readcyclecounter() - pr_c0; o[9] = wall_clock64() - pr_w0; } } while (0)
+#else
+#define BPROBE_BEGIN() do {} while (0)
+#define BPROBE_TILE() do {} while (0)
+#define BPROBE(k) do {} while (0)
+#define BPROBE_END() do {} while (0)
+#endif
+
 namespace {
 
 constexpr int BWAVES = 8;
@@ -379,6 +401,13 @@ __device__ __forceinline__ void mfma_vgpr(f32x16& acc, float a, float b) {
 __device__ __forceinline__ void mfma_vgpr_from_zero(f32x16& acc, float a, float b) {
   asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
 }
+// lane id recomputed where it is needed (2 VALU), opaque to the compiler: the staging roles derived from it (c4, rs,
+// byte offsets) then have short live ranges instead of being carried - and spilled - across the whole tile loop
+__device__ __forceinline__ int fresh_lane() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
 __device__ __forceinline__ void chain_fence(f32x16 (&acc)[2]) {
   asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0]), "+v"(acc[1]));
 }
@@ -411,40 +440,59 @@ __device__ __forceinline__ void fmma_chunk_from_regs(f32x16 (&dst)[2], const f32
     }
   }
 }
-// dst = W^T-tile * src (see mma_transposed_from_regs): the first MFMA of each output tile starts from the constant 0
+// dst = W^T-tile * src (see mma_transposed_from_regs): the first MFMA of each output tile starts from the constant 0;
+// the two column reads of step k + 2 are issued before the MFMAs of step k (two steps = 256 MFMA cycles of cover)
 __device__ __forceinline__ void fmma_transposed_from_regs(f32x16 (&dst)[2], const f32x16 (&src)[2], const float* wbuf, int i, int h) {
+  auto row_of = [&](int k) { return 32 * (k >> 4) + (k & 3) + 8 * ((k & 15) >> 2) + 4 * h; };  // k = 16 t + r
+  float w0[3], w1[3];
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int k = 0; k < 2; ++k) {
+    w0[k] = wbuf[row_of(k) * LDSW + i];
+    w1[k] = wbuf[row_of(k) * LDSW + 32 + i];
+  }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int n = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
-      const float w0 = wbuf[n * LDSW + i], w1 = wbuf[n * LDSW + 32 + i];
-      if (t == 0 && r == 0) {
-        mfma_vgpr_from_zero(dst[0], w0, src[t][r]);
-        mfma_vgpr_from_zero(dst[1], w1, src[t][r]);
-      } else {
-        mfma_vgpr(dst[0], w0, src[t][r]);
-        mfma_vgpr(dst[1], w1, src[t][r]);
-      }
+  for (int k = 0; k < 32; ++k) {
+    if (k + 2 < 32) {
+      w0[(k + 2) % 3] = wbuf[row_of(k + 2) * LDSW + i];
+      w1[(k + 2) % 3] = wbuf[row_of(k + 2) * LDSW + 32 + i];
     }
+    const float bsrc = src[k >> 4][k & 15];
+    if (k == 0) {
+      mfma_vgpr_from_zero(dst[0], w0[0], bsrc);
+      mfma_vgpr_from_zero(dst[1], w1[0], bsrc);
+    } else {
+      mfma_vgpr(dst[0], w0[k % 3], bsrc);
+      mfma_vgpr(dst[1], w1[k % 3], bsrc);
+    }
+  }
 }
 
 // acc[a][c] += sum over the tile's 32 rows of tm[row][32a + .] (x) tk[row][32c + .]; csum[a] += column sums of tm
 __device__ __forceinline__ void xty_tile(f32x16 (&acc)[2][2], float (&csum)[2], const float* tm, const float* tk, int i, int h) {
+  // software-pipelined by one step: the four column reads of step s + 1 are in flight under the four MFMAs of step s
+  float av[2], bv[2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) av[a] = tm[h * LDSW + 32 * a + i];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) bv[c] = tk[h * LDSW + 32 * c + i];
 #pragma unroll 4
   for (int s = 0; s < RPW / 2; ++s) {
-    float av[2], bv[2];
+    float na[2], nb[2];
+    const int sn = s + 1 < RPW / 2 ? s + 1 : s;  // the last step re-reads its own row (never used)
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      av[a] = tm[(2 * s + h) * LDSW + 32 * a + i];
-      csum[a] += av[a];
-    }
+    for (int a = 0; a < 2; ++a) na[a] = tm[(2 * sn + h) * LDSW + 32 * a + i];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) bv[c] = tk[(2 * s + h) * LDSW + 32 * c + i];
+    for (int c = 0; c < 2; ++c) nb[c] = tk[(2 * sn + h) * LDSW + 32 * c + i];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) csum[a] += av[a];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int c = 0; c < 2; ++c) mfma_agpr(acc[a][c], av[a], bv[c]);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) av[a] = na[a];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) bv[c] = nb[c];
   }
 }
 
@@ -467,9 +515,14 @@ __global__ __launch_bounds__(FNT) void mlp_backward_fused_kernel(const gnc_mlp_d
   const int rows = (int)d.rows;
   float* wres = lds;                                   // 3 weight chunks: W0 (its MATMUL columns), W1, W2
   float* pbuf = lds + 3 * CH;                          // biases 0..2, gamma, beta
-  float* te = pbuf + (L + 2) * PSTRIDE + wave * 3 * RPW * LDSW;  // the tile's input rows (kept for dW0)
-  float* ta = te + RPW * LDSW;                         // working tile A
-  float* tb = ta + RPW * LDSW;                         // working tile B
+  // The wave's three row tiles.  Their offsets are made opaque to the compiler: left alone it addresses all three from
+  // ONE base register plus constants beyond the 16-bit offset field of the DS instructions (the tiles sit above 64 KB),
+  // which costs a v_add_u32 per LDS access in the column-read loops; with one base per tile every access is base +
+  // immediate.
+  int te_o = 3 * CH + (L + 2) * PSTRIDE + wave * 3 * RPW * LDSW, ta_o = te_o + RPW * LDSW, tb_o = te_o + 2 * RPW * LDSW;
+  float* te = lds + te_o;                              // the tile's input rows (kept for dW0)
+  float* ta = lds + ta_o;                              // working tile A
+  float* tb = lds + tb_o;                              // working tile B
 
   stage_params<FNT>(pbuf, d, PSTRIDE, tid);
   {
@@ -501,6 +554,8 @@ __global__ __launch_bounds__(FNT) void mlp_backward_fused_kernel(const gnc_mlp_d
 
   auto to_tile = [&](float* t, const f32x4 (&pre)[NP], int width) {  // whole-row pieces -> LDS tile, zero beyond `width`
     compiler_lds_barrier();
+    const int fl = fresh_lane();
+    const int c4 = fl & 15, rs = fl >> 4;
     const int c = c4 * 4;
     if (width >= KC) {  // wave-uniform: the full-width case carries no masks
 #pragma unroll
@@ -563,8 +618,8 @@ __global__ __launch_bounds__(FNT) void mlp_backward_fused_kernel(const gnc_mlp_d
   load_tile_rows(pg, b.grad_out, b.ld_grad_out, wt0 * RPW, rows, g_off);
   gather_rows_of(pa, pb);
   // park a tile's rows in the wave's LDS tiles: e -> te, grad_out -> tb, the sum of the gathered projections -> ta
-  auto park = [&]() {
-    to_tile(te, pe, s0.width);
+  auto park = [&](bool with_e) {
+    if (with_e) to_tile(te, pe, s0.width);
     to_tile(tb, pg, out_dim);
     if constexpr (NADD > 0) {
 #pragma unroll
@@ -572,8 +627,10 @@ __global__ __launch_bounds__(FNT) void mlp_backward_fused_kernel(const gnc_mlp_d
       to_tile(ta, pa, d.seg[1].width);
     }
   };
-  park();
+  park(true);
+  BPROBE_BEGIN();
   for (int wt = wt0; wt < num_wtiles; wt += total_waves) {
+    BPROBE_TILE();
     const int row0 = wt * RPW;
     const int nrow0 = (wt + total_waves) * RPW;  // may lie past the end: windows return zeros, ids are clamped
     if constexpr (NADD > 0) {
@@ -587,11 +644,13 @@ __global__ __launch_bounds__(FNT) void mlp_backward_fused_kernel(const gnc_mlp_d
     chain_fence(a0);
     if constexpr (NADD > 0) add_tile_from_lds<HT>(a0, ta, i, h);
     relu_tiles<HT>(a0);
+    BPROBE(0);  // first Linear + additive rows + ReLU
     f32x16 a1[HT];
     init_bias<HT>(a1, pbuf + PSTRIDE, h);
     fmma_chunk_from_regs(a1, a0, wres + CH, d.in_dim[1], i, h);
     chain_fence(a1);
     relu_tiles<HT>(a1);
+    BPROBE(1);  // second Linear + ReLU
     // ---------------------------------------------------------------- grad of the pre-LayerNorm output
     f32x16 g[HT];
     tile_from_lds<HT>(g, tb, i, h);
@@ -615,10 +674,12 @@ __global__ __launch_bounds__(FNT) void mlp_backward_fused_kernel(const gnc_mlp_d
 #pragma unroll
         for (int r = 0; r < 16; ++r) g[t][r] = (feat_of(t, r, h) < out_dim) ? g[t][r] : 0.f;
     }
+    BPROBE(2);  // third Linear + LayerNorm backward + parameter sums
     // ---------------------------------------------------------------- layer 2: dW2 += dz2^T a1, da1 = W2^T dz2
     acc_to_tile(tb, g);
     acc_to_tile(ta, a1);
     xty_tile(dW2, cs2, tb, ta, i, h);
+    BPROBE(3);  // transposes + dW2
     {
       f32x16 da[HT];
       fmma_transposed_from_regs(da, g, wres + 2 * CH, i, h);
@@ -627,6 +688,7 @@ __global__ __launch_bounds__(FNT) void mlp_backward_fused_kernel(const gnc_mlp_d
 #pragma unroll
       for (int t = 0; t < HT; ++t) g[t] = da[t];
     }
+    BPROBE(4);  // da1 + mask
     // a1 is dead: the next tile's e and grad_out rows are requested here and land under layers 1 and 0
     load_tile_rows(pe, s0.ptr, s0.ld, nrow0, rows, e_off);
     load_tile_rows(pg, b.grad_out, b.ld_grad_out, nrow0, rows, g_off);
@@ -642,42 +704,54 @@ __global__ __launch_bounds__(FNT) void mlp_backward_fused_kernel(const gnc_mlp_d
 #pragma unroll
       for (int t = 0; t < HT; ++t) g[t] = da[t];
     }
+    BPROBE(5);  // load issue + layer 1 (transposes, dW1, da0, mask)
     // a0 is dead: the next tile's gathered rows, and this tile's grad_out rows again for the residual path of dx
     gather_rows_of(pa, pb);
-    f32x4 gres[NP];
-    if (b.dx && b.dx_add_grad_out) load_tile_rows(gres, b.grad_out, b.ld_grad_out, row0, rows, g_off);
     // ---------------------------------------------------------------- layer 0: dW0 += dz0^T e, dz0 out, dx
     acc_to_tile(tb, g);
     xty_tile(dW0, cs0, tb, te, i, h);
+    to_tile(te, pe, s0.width);  // this tile's e rows are done with: the next tile's (requested two layers ago) move in
+    f32x4 gres[NP];  // requested as late as the dx product still covers (L2 / MALL hits): 32 registers less under dW0
+    if (b.dx && b.dx_add_grad_out) {
+      const int flg = fresh_lane();
+      load_tile_rows(gres, b.grad_out, b.ld_grad_out, row0, rows,
+                     (uint32_t)((flg >> 4) * b.ld_grad_out + ((flg & 15) * 4 < out_dim ? (flg & 15) * 4 : 0)) * 4u);
+    }
     f32x16 dxs[HT];
     if (b.dx) {
       fmma_transposed_from_regs(dxs, g, wres, i, h);
       chain_fence(dxs);
       acc_to_tile(ta, dxs);
     }
+    BPROBE(6);  // gather issue + layer 0 (transpose, dW0, dx)
     // everything requested above is collected before the asm stores join the memory queue
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-      asm volatile("" ::"v"(pe[p]), "v"(pg[p]));
+      asm volatile("" ::"v"(pg[p]));
       if constexpr (NADD > 0) asm volatile("" ::"v"(pa[p]), "v"(pb[p]));
     }
     asm volatile("" ::"v"(ids_nxt[0]), "v"(ids_nxt[1]));
-    if (b.dz[0]) store_staged_rows(tb, b.dz[0], d.out_dim[0], d.out_dim[0], row0, rows, c4, rs);
-    if (b.dx) {
-      if (b.dx_add_grad_out) {
-        compiler_lds_barrier();
+    // the residual path of dx BEFORE any store is issued: its grad_out rows are the youngest load, the compiler can
+    // only wait for them with vmcnt(0), and behind a store that wait would sit out the store's HBM round trip
+    // (measured with the phase probe: 4.7k of a tile's 52k cycles)
+    const int fle = fresh_lane();
+    const int c4e = fle & 15, rse = fle >> 4;
+    if (b.dx && b.dx_add_grad_out) {
+      compiler_lds_barrier();
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
-          float* q = ta + (p * 4 + rs) * LDSW + c4 * 4;
-          *reinterpret_cast<f32x4*>(q) = *reinterpret_cast<const f32x4*>(q) + gres[p];
-        }
-        compiler_lds_barrier();
+      for (int p = 0; p < NP; ++p) {
+        float* q = ta + (p * 4 + rse) * LDSW + c4e * 4;
+        *reinterpret_cast<f32x4*>(q) = *reinterpret_cast<const f32x4*>(q) + gres[p];
       }
-      store_staged_rows(ta, b.dx + s0.wcol, b.ld_dx, s0.width, row0, rows, c4, rs);
+      compiler_lds_barrier();
     }
+    if (b.dz[0]) store_staged_rows(tb, b.dz[0], d.out_dim[0], d.out_dim[0], row0, rows, c4e, rse);
+    if (b.dx) store_staged_rows(ta, b.dx + s0.wcol, b.ld_dx, s0.width, row0, rows, c4e, rse);
     compiler_lds_barrier();
-    park();  // the next tile's rows (requested above, long landed) into the tiles this one has finished with
+    park(false);  // the rest of the next tile's rows (requested above, long landed) into the tiles this one has finished with
+    BPROBE(7);  // collect loads + stores + park
   }
+  BPROBE_END();
 
   // ------------------------------------------------------------------ one row of partials per wave and layer
   agpr_mfma_fence();  // the last asm-issued MFMAs have written their accumulators before anything reads them

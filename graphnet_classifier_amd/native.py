@@ -106,11 +106,12 @@ def load_library() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("GNC_LIB_PATH", LIB_PATH)  # developer override: A/B builds and the phase-probe build
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             f"or `make -C graphnet_classifier_amd/csrc`.  There is no CPU/PyTorch fallback for the hot path.")
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here means the header and the library disagree
         fn.restype = res
