@@ -401,13 +401,6 @@ __device__ __forceinline__ void mfma_vgpr(f32x16& acc, float a, float b) {
 __device__ __forceinline__ void mfma_vgpr_from_zero(f32x16& acc, float a, float b) {
   asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
 }
-// lane id recomputed where it is needed (2 VALU), opaque to the compiler: the staging roles derived from it (c4, rs,
-// byte offsets) then have short live ranges instead of being carried - and spilled - across the whole tile loop
-__device__ __forceinline__ int fresh_lane() {
-  int l;
-  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
-  return l;
-}
 __device__ __forceinline__ void chain_fence(f32x16 (&acc)[2]) {
   asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0]), "+v"(acc[1]));
 }

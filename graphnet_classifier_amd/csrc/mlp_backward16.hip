@@ -309,29 +309,31 @@ __global__ __launch_bounds__(NT16) void mlp_backward_stream16_kernel(const gnc_m
     // ------------------------------------------------------------------ forward recompute: first Linear
     f32x4 hid[NTL];
     init_bias16<NTL>(hid, pbuf, g);
-    for (int st = 0; st < pl.num_steps; ++st) {
-      const int s = pl.step[st].seg, c0 = pl.step[st].c0;
-      const int width = d.seg[s].width;
-      stage(cur, c0, width);
+    auto stage_and_advance = [&](int st) {
+      stage(cur, pl.step[st].c0, d.seg[pl.step[st].seg].width);
       if (st + 1 < pl.num_steps) load_step(cur, st + 1, tile);
       else load_rows(cur, b.grad_out, b.ld_grad_out, nullptr, 0, 0, 0, tile);  // first grad_out slab
-      if (pl.step[st].add) {
-        const int t0 = c0 >> 4;
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(abuf + i * LDSW + 16 * cb + 4 * g);
-#pragma unroll
-          for (int t = 0; t < NTL; ++t)
-            if (t == t0 + cb) hid[t] += v;
-        }
-      } else {
-        prefetch_next_chunk(q);
-        const int kc = width - c0 < KC ? width - c0 : KC;
-        mma16_chunk_from_lds<NTL>(hid, abuf, wbuf, (kc + 15) >> 4, i, g);
-        publish_next_chunk();
-        ++q;
-      }
+    };
+    int st = 0;
+    for (; st < pl.num_steps && !pl.step[st].add; ++st) {
+      const int c0 = pl.step[st].c0, width = d.seg[pl.step[st].seg].width;
+      stage_and_advance(st);
+      prefetch_next_chunk(q);
+      const int kc = width - c0 < KC ? width - c0 : KC;
+      mma16_chunk_from_lds<NTL>(hid, abuf, wbuf, (kc + 15) >> 4, i, g);
+      publish_next_chunk();
+      ++q;
     }
+    // additive steps, slab-major in the plan: static accumulator tile index (see mlp_stream16.hip)
+#define GNC_ADD_SLAB(CC_)                                                        \
+  if constexpr (CC_ < NCH) {                                                    \
+    for (; st < pl.num_steps && pl.step[st].c0 == CC_ * KC; ++st) {               \
+      stage_and_advance(st);                                                     \
+      add_slab16<NTL, 4 * CC_>(hid, abuf, i, g);                                  \
+    }                                                                            \
+  }
+    GNC_ADD_SLAB(0) GNC_ADD_SLAB(1) GNC_ADD_SLAB(2) GNC_ADD_SLAB(3)
+#undef GNC_ADD_SLAB
     unsigned mask[GNC_MAX_LINEAR - 1][MW];
     relu_mask16<NTL>(hid, mask[0]);
     emit(hid, b.act[0], d.out_dim[0], d.out_dim[0], row0);
@@ -463,22 +465,23 @@ bool make_plan(const gnc_mlp_desc_t& d, bool want_dx, BPlan16* pl) {
   }
   if (wmax > 256) return false;
   *pl = BPlan16{};
-  for (int pass = 0; pass < 2; ++pass)  // MATMUL segments first, then the additive ones
+  for (int s = 0; s < d.num_segments; ++s) {  // MATMUL segments first, chunk by chunk
+    const gnc_mlp_segment_t& sg = d.seg[s];
+    if (sg.ld % 4 != 0 || !al16b(sg.ptr)) return false;
+    if (sg.index && (sg.table_rows <= 0 || sg.table_rows * (int64_t)sg.ld * 4 > 0xffffffffll)) return false;
+    if (sg.mode == GNC_SEG_ADD) continue;
+    if (sg.wcol % 4 != 0) return false;
+    for (int c0 = 0; c0 < sg.width; c0 += KC) {
+      if (pl->num_steps >= B16_MAX_STEPS || pl->num_wchunks >= B16_MAX_WCHUNKS) return false;
+      pl->step[pl->num_steps++] = {(short)s, (short)c0, (short)0, 0};
+      pl->wc[pl->num_wchunks++] = {(short)0, (short)(sg.wcol + c0), (short)(sg.wcol + sg.width), 0};
+    }
+  }
+  for (int c0 = 0; c0 < d.out_dim[0]; c0 += KC)  // then the additive ones, slab-major
     for (int s = 0; s < d.num_segments; ++s) {
-      const gnc_mlp_segment_t& sg = d.seg[s];
-      if (sg.ld % 4 != 0 || !al16b(sg.ptr)) return false;
-      if (sg.index && (sg.table_rows <= 0 || sg.table_rows * (int64_t)sg.ld * 4 > 0xffffffffll)) return false;
-      const bool add = sg.mode == GNC_SEG_ADD;
-      if ((pass == 1) != add) continue;
-      if (!add && sg.wcol % 4 != 0) return false;
-      for (int c0 = 0; c0 < sg.width; c0 += KC) {
-        if (pl->num_steps >= B16_MAX_STEPS) return false;
-        pl->step[pl->num_steps++] = {(short)s, (short)c0, (short)(add ? 1 : 0), 0};
-        if (!add) {
-          if (pl->num_wchunks >= B16_MAX_WCHUNKS) return false;
-          pl->wc[pl->num_wchunks++] = {(short)0, (short)(sg.wcol + c0), (short)(sg.wcol + sg.width), 0};
-        }
-      }
+      if (d.seg[s].mode != GNC_SEG_ADD) continue;
+      if (pl->num_steps >= B16_MAX_STEPS) return false;
+      pl->step[pl->num_steps++] = {(short)s, (short)c0, (short)1, 0};
     }
   if (pl->num_wchunks == 0) return false;
   const int mm_chunks = pl->num_wchunks;

@@ -417,6 +417,15 @@ __device__ __forceinline__ void store_tiles(f32x16 (&o)[OT], float* abuf, const 
 // ---- helpers of the FAST (ReLU, aligned, unconditional-load) kernels ---------------------------------
 constexpr int NP = RPW / 4;  // row groups per staging pass: 16 lanes x 16 B per row, 4 rows per instruction
 
+// Lane id recomputed where it is needed (2 VALU), opaque to the compiler: the staging roles derived from it (c4, rs,
+// byte offsets, LDS addresses) then have short live ranges instead of being hoisted out of the tile loop, carried
+// across it and - in the kernels that sit at their register limit - spilled to scratch and reloaded inside it.
+__device__ __forceinline__ int fresh_lane() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+
 __device__ __forceinline__ void compiler_lds_barrier() {
   // LDS operations of one wave execute in issue order, so a later ds_read sees an earlier
   // ds_write of another lane without any wait; only the COMPILER must not reorder them.

@@ -30,6 +30,16 @@ __device__ __forceinline__ void relu16(f32x4 (&acc)[NTL]) {
   }
 }
 
+// acc[T0 + cb] += the staged rows' columns [16 cb, 16 cb + 16) for cb = 0..3: one 64-column slab of an additive segment.
+// T0 is a template argument (the plans list additive steps slab-major and the kernels walk the slabs with a static
+// index): with a run-time tile index every accumulator would go through a v_cndmask per component - ~320 vector
+// instructions per slab instead of 16.
+template <int NTL, int T0>
+__device__ __forceinline__ void add_slab16(f32x4 (&acc)[NTL], const float* abuf, int i, int g) {
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb)
+    if (T0 + cb < NTL) acc[T0 + cb < NTL ? T0 + cb : 0] += *reinterpret_cast<const f32x4*>(abuf + i * LDSW + 16 * cb + 4 * g);
+}
 // acc[t] += W_chunk[16t + i][16cb + 4g + s] * X[j][16cb + 4g + s]: one staged 64-column chunk of the first Linear
 template <int NTL>
 __device__ __forceinline__ void mma16_chunk_from_lds(f32x4 (&acc)[NTL], const float* abuf, const float* wbuf, int kc16,

@@ -45,10 +45,6 @@ __global__ __launch_bounds__(NT16) void mlp_stream16_kernel(const gnc_mlp_desc_t
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15;   // feature row of the A operand == data row of the B operand / accumulator column
   const int g = lane >> 4;
-  const int c4 = lane & 15;  // staging role
-  const int rs = lane >> 4;
-  const int wc4 = tid & 15;
-  const int wr0 = tid >> 4;
   const int L = d.num_linear;
   const int out_dim = d.out_dim[L - 1];
   const int rows = (int)d.rows;
@@ -60,6 +56,8 @@ __global__ __launch_bounds__(NT16) void mlp_stream16_kernel(const gnc_mlp_desc_t
   stage_params<NT16>(pbuf, d, PSTRIDE, tid);
 
   auto wload = [&](f32x4 (&wr)[NW], int q) {
+    const int ftid = wave * 64 + fresh_lane();  // roles recomputed per use: nothing lane-derived is carried across the loop
+    const int wc4 = ftid & 15, wr0 = ftid >> 4;
     const int layer = pl.wc[q].layer;
     const float* W = d.weight[layer];
     const int ldw = ldw_of(d, layer);
@@ -90,6 +88,8 @@ __global__ __launch_bounds__(NT16) void mlp_stream16_kernel(const gnc_mlp_desc_t
     }
   };
   auto wstore = [&](const f32x4 (&wr)[NW], float* buf) {
+    const int ftid = wave * 64 + fresh_lane();
+    const int wc4 = ftid & 15, wr0 = ftid >> 4;
 #pragma unroll
     for (int p = 0; p < NW; ++p) *reinterpret_cast<f32x4*>(buf + (p * RPP + wr0) * LDSW + wc4 * 4) = wr[p];
   };
@@ -102,6 +102,8 @@ __global__ __launch_bounds__(NT16) void mlp_stream16_kernel(const gnc_mlp_desc_t
     return ip ? ip[r] : r;
   };
   auto load_rows = [&](f32x4 (&pre)[NP16], int s, int c0, int idxv, int tile_of) {
+    const int fl = fresh_lane();
+    const int c4 = fl & 15, rs = fl >> 4;
     const float* base = d.seg[s].ptr;
     const int ld = d.seg[s].ld;
     const int col = c0 + c4 * 4 < ld ? c0 + c4 * 4 : 0;
@@ -129,6 +131,8 @@ __global__ __launch_bounds__(NT16) void mlp_stream16_kernel(const gnc_mlp_desc_t
   };
   auto stage = [&](const f32x4 (&pre)[NP16], int c0, int width) {
     compiler_lds_barrier();
+    const int fl = fresh_lane();
+    const int c4 = fl & 15, rs = fl >> 4;
     const int c = c0 + c4 * 4;
     if (c0 + KC <= width) {  // full chunk: nothing to mask
 #pragma unroll
@@ -186,39 +190,41 @@ __global__ __launch_bounds__(NT16) void mlp_stream16_kernel(const gnc_mlp_desc_t
     // ------------------------------------------------------------------ first Linear
     f32x4 hid[NTH];
     init_bias16<NTH>(hid, pbuf, g);
-    for (int st = 0; st < pl.num_steps; ++st) {
-      const int s = pl.step[st].seg, c0 = pl.step[st].c0;
-      const int width = d.seg[s].width;
-      stage(cur, c0, width);
-      {
-        const bool wrap = st + 1 >= pl.num_steps;
-        const int nst = wrap ? 0 : st + 1;
-        if (wrap) {
+    // stage the rows of step `st` and request those of the step after it (the next tile's first one after the last)
+    auto stage_and_advance = [&](int st) {
+      stage(cur, pl.step[st].c0, d.seg[pl.step[st].seg].width);
+      const bool wrap = st + 1 >= pl.num_steps;
+      const int nst = wrap ? 0 : st + 1;
+      if (wrap) {
 #pragma unroll
-          for (int k = 0; k < GNC_MAX_SEGMENTS; ++k) {
-            ids[k] = ids_next[k];
-            if (k < d.num_segments) ids_next[k] = load_idx(ntile + (int)gridDim.x, k);
-          }
+        for (int k = 0; k < GNC_MAX_SEGMENTS; ++k) {
+          ids[k] = ids_next[k];
+          if (k < d.num_segments) ids_next[k] = load_idx(ntile + (int)gridDim.x, k);
         }
-        load_rows(cur, pl.step[nst].seg, pl.step[nst].c0, id_of(pl.step[nst].seg), wrap ? ntile : tile);
       }
-      if (pl.step[st].add) {  // rows already in the hidden width: acc[t] += staged columns (tile t = c0/16 + cb)
-        const int t0 = c0 >> 4;
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(abuf + i * LDSW + 16 * cb + 4 * g);
-#pragma unroll
-          for (int t = 0; t < NTH; ++t)
-            if (t == t0 + cb) hid[t] += v;  // wave-uniform select; unrolled so the register index stays static
-        }
-      } else {
-        prefetch_next_chunk(q);
-        const int kc = width - c0 < KC ? width - c0 : KC;
-        mma16_chunk_from_lds<NTH>(hid, abuf, cur_w(), (kc + 15) >> 4, i, g);
-        publish_next_chunk();
-        ++q;
-      }
+      load_rows(cur, pl.step[nst].seg, pl.step[nst].c0, id_of(pl.step[nst].seg), wrap ? ntile : tile);
+    };
+    int st = 0;
+    for (; st < pl.num_steps && !pl.step[st].add; ++st) {  // MATMUL steps: one staged 64-column chunk of weight[0] each
+      const int c0 = pl.step[st].c0, width = d.seg[pl.step[st].seg].width;
+      stage_and_advance(st);
+      prefetch_next_chunk(q);
+      const int kc = width - c0 < KC ? width - c0 : KC;
+      mma16_chunk_from_lds<NTH>(hid, abuf, cur_w(), (kc + 15) >> 4, i, g);
+      publish_next_chunk();
+      ++q;
     }
+    // additive steps (rows already in the hidden width), listed slab-major by the plan: the accumulator tiles a slab
+    // goes to are a compile-time constant here (a run-time tile index costs a v_cndmask per accumulator component)
+#define GNC_ADD_SLAB(CC_)                                                        \
+  if constexpr (CC_ < NCHI) {                                                    \
+    for (; st < pl.num_steps && pl.step[st].c0 == CC_ * KC; ++st) {               \
+      stage_and_advance(st);                                                     \
+      add_slab16<NTH, 4 * CC_>(hid, abuf, i, g);                                  \
+    }                                                                            \
+  }
+    GNC_ADD_SLAB(0) GNC_ADD_SLAB(1) GNC_ADD_SLAB(2) GNC_ADD_SLAB(3)
+#undef GNC_ADD_SLAB
 
     f32x4 o[NTO];
     if (L == 1) {
@@ -267,6 +273,8 @@ __global__ __launch_bounds__(NT16) void mlp_stream16_kernel(const gnc_mlp_desc_t
     for (int p = 0; p < NP16; ++p) asm volatile("" ::"v"(cur[p]));
 
     // ------------------------------------------------------------------ epilogue: 64 output columns at a time
+    const int fle = fresh_lane();
+    const int c4 = fle & 15, rs = fle >> 4;
 #pragma unroll
     for (int cc = 0; cc < NCHO; ++cc) {
       if (cc * KC < out_dim) {
@@ -324,21 +332,22 @@ int gnc_mlp::launch_stream16(const gnc_mlp_desc_t& d, hipStream_t stream, bool* 
   for (int l = 0; l < L; ++l)
     if (ldw_of(d, l) % 4 != 0 || !al16p(d.weight[l])) return GNC_OK;
   Plan16 pl = {};
-  for (int pass = 0; pass < 2; ++pass)  // MATMUL segments first, then the additive ones
+  for (int s = 0; s < d.num_segments; ++s) {  // MATMUL segments first, chunk by chunk
+    const gnc_mlp_segment_t& sg = d.seg[s];
+    if (sg.ld % 4 != 0 || !al16p(sg.ptr)) return GNC_OK;
+    if (sg.mode == GNC_SEG_ADD) continue;
+    if (sg.wcol % 4 != 0) return GNC_OK;
+    for (int c0 = 0; c0 < sg.width; c0 += KC) {
+      if (pl.num_steps >= MAX_STEPS16 || pl.num_wchunks >= MAX_WCHUNKS16) return GNC_OK;
+      pl.step[pl.num_steps++] = {(short)s, (short)c0, (short)0, 0};
+      pl.wc[pl.num_wchunks++] = {(short)0, (short)(sg.wcol + c0), (short)(sg.wcol + sg.width), 0};
+    }
+  }
+  for (int c0 = 0; c0 < H; c0 += KC)  // then the additive ones, slab-major (the kernel walks the slabs with a static index)
     for (int s = 0; s < d.num_segments; ++s) {
-      const gnc_mlp_segment_t& sg = d.seg[s];
-      if (sg.ld % 4 != 0 || !al16p(sg.ptr)) return GNC_OK;
-      const bool add = sg.mode == GNC_SEG_ADD;
-      if ((pass == 1) != add) continue;
-      if (!add && sg.wcol % 4 != 0) return GNC_OK;
-      for (int c0 = 0; c0 < sg.width; c0 += KC) {
-        if (pl.num_steps >= MAX_STEPS16) return GNC_OK;
-        pl.step[pl.num_steps++] = {(short)s, (short)c0, (short)(add ? 1 : 0), 0};
-        if (!add) {
-          if (pl.num_wchunks >= MAX_WCHUNKS16) return GNC_OK;
-          pl.wc[pl.num_wchunks++] = {(short)0, (short)(sg.wcol + c0), (short)(sg.wcol + sg.width), 0};
-        }
-      }
+      if (d.seg[s].mode != GNC_SEG_ADD) continue;
+      if (pl.num_steps >= MAX_STEPS16) return GNC_OK;
+      pl.step[pl.num_steps++] = {(short)s, (short)c0, (short)1, 0};
     }
   if (pl.num_wchunks == 0) return GNC_OK;
   for (int l = 1; l < L; ++l)

@@ -34,6 +34,29 @@ for name, (x, pos, ei) in cases.items():
         out = cap(xd)
         torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
     print(f"{name:36s} hipGraph replay (device input) median {1e3*np.median(ts[5:]):7.3f} ms", flush=True)
+    # the reference's regime: ONE graph per optimizer step (main.py:60).  eager = torch.optim.Adam over 76 tensors and a
+    # loss.item() per step (utils/train_model.py:37-44); fused = flat parameters + one fused Adam launch, loss kept on
+    # the device; captured = the whole step (forward + CE + backward + gradient pack + Adam) replayed from one hipGraph
+    from graphnet_classifier_amd.train import CapturedTrainStep, FlatParameters, FusedAdam
+    tmodel = CombinedModel(GraphNet(num_local_features=3, space_dim=2, out_channels=1, n_blocks=3), num_nodes=x.size(0), classes=2)
+    tmodel.train()
+    fopt = FusedAdam(FlatParameters(tmodel), lr=1e-3)
+    loss_sum = torch.zeros((), dtype=torch.float64, device="cuda:0")
+    cap_step = CapturedTrainStep(tmodel, fopt, crit, (x, pos, ei), label, loss_sum)
+    xdev, posdev, labdev = x.to("cuda:0"), pos.to("cuda:0"), label.to("cuda:0")
+    for mode in ("fused", "captured"):
+        ts = []
+        for it in range(60):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            if mode == "fused":
+                logits = tmodel((xdev, posdev, ei))
+                loss = crit(logits, labdev)
+                fopt.zero_grad(); loss.backward(); fopt.step()
+                loss_sum += loss.detach().double()
+            else:
+                cap_step((x, pos, ei), label)  # host tensors in, as the reference's loader yields them
+            torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+        print(f"{name:36s} train/{mode:8s} median {1e3*np.median(ts[5:]):7.3f} ms  min {1e3*np.min(ts[5:]):7.3f} ms", flush=True)
     model.train()
     for mode in ("forward", "train"):
         ts = []
