@@ -38,6 +38,7 @@ sys.path.insert(0, ROOT)
 from graphnet_classifier_amd import native, synthetic  # noqa: E402
 from graphnet_classifier_amd.GNN import GraphNet  # noqa: E402
 from graphnet_classifier_amd.sharding import shard_ranges  # noqa: E402
+from graphnet_classifier_amd import topology  # noqa: E402
 from graphnet_classifier_amd.topology import clear_topology_cache  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -110,6 +111,10 @@ def main():
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
                     help="strong (default): one workload split by graph id over the ranks (c3 over N GPUs = BASELINE config c4); "
                          "weak: every rank its own full-size batch")
+    ap.add_argument("--validation", default="deferred", choices=["deferred", "sync"],
+                    help="how the step reports an out-of-range edge_index: deferred (default) = the flags the topology build "
+                         "computes stay on the device and are read once after the timed region (no host sync inside a step, the "
+                         "host enqueues ahead of the GPU); sync = read back in every step, as the module API does by default")
     ap.add_argument("--train-steps", type=int, default=5,
                     help="training steps of the extra `train` leg after the timed forward region (0 = skip it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -140,6 +145,7 @@ def main():
             dist.init_process_group(backend)
 
     native.load_library()
+    topology.set_validation(a.validation)
     w = synthetic.WORKLOADS[a.workload]
     n_blocks = w["n_blocks"]
     if a.scaling == "weak":
@@ -254,13 +260,26 @@ def main():
         marks[k + 1].record()
     fence()
     elapsed = time.perf_counter() - t0
+    topology.check_deferred()  # the out-of-range flags of every timed step, read with one sync (raises IndexError if set)
     y_fwd = y
     device_allocs_timed = torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - allocs0
     per_step_order = [marks[k].elapsed_time(marks[k + 1]) for k in range(a.steps)]
     per_step = sorted(per_step_order)
     # (not part of `value`) the same step with the topology cached: SURVEY 8d asks for the throughput with and
     # without the CSR build
-    cached_ms = None
+    cached_ms = sync_ms = None
+    if a.mode == "forward" and a.validation == "deferred":  # the same step with the flags read back in every step
+        native.set_kernel_timers(None)
+        topology.set_validation("sync")
+        step()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        fence()
+        sync_ms = (time.perf_counter() - t1) / a.steps * 1e3
+        topology.set_validation("deferred")
+        native.set_kernel_timers(timers)
     if a.mode == "forward":
         native.set_kernel_timers(None)
         with torch.no_grad():
@@ -315,6 +334,7 @@ def main():
             tstep()
         fence()
         t_train, train_steps = time.perf_counter() - tt0, a.train_steps
+        topology.check_deferred()
         ar_ms = sum(e0.elapsed_time(e1) for e0, e1 in ar_events["events"]) / train_steps
         collectives = flat_params.reducer.collectives - c0
 
@@ -401,6 +421,12 @@ def main():
                 "allreduce_ms": ar_ms if world > 1 else 0.0, "gradient_pack_ms": ar_ms if world == 1 else None,
                 "allreduce_bytes": flat_params.grad.numel() * 4, "collectives_per_step": collectives / train_steps,
                 "backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None}
+        result["config"]["topology_validation"] = ("deferred: the out-of-range flags of each step's CSR build stay on the device and are "
+                                                    "read once after the timed region" if a.validation == "deferred" else
+                                                    "sync: flags read back (one host sync) inside every step")
+        if sync_ms is not None:
+            result["validated_every_step"] = {"ms_per_step": sync_ms, "value": tot_edges * n_blocks / (sync_ms * 1e-3),
+                                              "note": "same step with --validation sync: one host sync per step (rank 0's clock)"}
         if cached_ms is not None:
             result["topology_cached"] = {"ms_per_step": cached_ms, "value": tot_edges * n_blocks / (cached_ms * 1e-3),
                                          "note": "same step without the CSR build (rank 0's clock)"}

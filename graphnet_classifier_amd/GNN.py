@@ -261,7 +261,10 @@ class GraphNet(nn.Module):
         out = self.node_encoder.forward_segments([(x.view(x.size(0), -1), None)])         # :305
         edge_attr = self.edge_encoder.forward_segments([(edge_attr, None)])               # :306
         out, _ = self.graph_processor.forward_sorted(out, topo, edge_attr)                # :307
-        return self.node_decoder.forward_segments([(out, None)])                          # :308
+        out = self.node_decoder.forward_segments([(out, None)])                           # :308
+        if topo.deferred:  # validation not read back yet: a bad edge_index must not yield a plausible result
+            out = torch.where(topo.status.any(), torch.full_like(out, float("nan")), out)
+        return out
 
     def forward(self, x, pos, edge_index):
         dev = require_gpu_param(self.node_encoder.model[0].weight, "GraphNet")

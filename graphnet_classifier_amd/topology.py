@@ -25,10 +25,40 @@ import torch
 from . import native
 
 
+# How an out-of-range node id in ``edge_index`` is reported (the reference raises IndexError inside its scatter's
+# ``index_add_``, models/GNN.py:18-20):
+#   "sync"     (default) the topology build reads its two device flags back - one host sync per build - and raises;
+#   "deferred" the build does NOT synchronise: the flags stay on the device, the kernels run on sanitised ids (never a
+#              fault), ``GraphNet`` poisons its output with NaN on the device when a flag is set, and
+#              ``check_deferred()`` - called by whoever next synchronises anyway (bench.py: after the timed region) -
+#              reads every pending flag with one sync and raises the IndexError then.  This is what lets the host run
+#              ahead of the GPU across steps (small per-rank batches of a strong-scaling run are launch-bound otherwise).
+_VALIDATION = "sync"
+_pending: list = []
+
+
+def set_validation(mode: str) -> None:
+    global _VALIDATION
+    if mode not in ("sync", "deferred"):
+        raise ValueError("validation mode must be 'sync' or 'deferred'")
+    _VALIDATION = mode
+
+
+def check_deferred() -> None:
+    """Read every pending out-of-range flag (one host sync) and raise the IndexError a synchronous build would have."""
+    global _pending
+    flags, _pending = _pending, []
+    if flags:
+        bad = torch.stack([f.any() for f, _ in flags]).tolist()
+        for is_bad, (_, n) in zip(bad, flags):
+            if is_bad:
+                raise IndexError(f"edge_index has node ids outside [0, {n})")
+
+
 class GraphTopology:
     """Device-resident CSR view of one ``edge_index`` [2, E] (int64) over ``num_nodes`` nodes."""
 
-    def __init__(self, edge_index: torch.Tensor, num_nodes: int, device=None, validate: bool = True):
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int, device=None, validate: bool | str = True):
         if edge_index.dim() != 2 or edge_index.size(0) != 2:
             raise ValueError(f"edge_index must be [2, E], got {tuple(edge_index.shape)}")
         device = torch.device(device) if device is not None else edge_index.device
@@ -47,12 +77,19 @@ class GraphTopology:
         self._col32 = None
         self._inv_perm = None
         self._csc = None
-        if validate:
+        self.status = status  # device int32 [2]: out-of-range destination / source flags
+        mode = _VALIDATION if validate is True else validate
+        if mode == "deferred":
+            _pending.append((status, self.num_nodes))
+            if len(_pending) > 4096:
+                check_deferred()
+        elif mode:
             # one host sync per topology build; the reference syncs on every scatter
             # (models/GNN.py:16-17 `index.max().item()`) and raises IndexError for a bad index
             bad_dst, bad_src = status.tolist()  # both flags, one sync
             if bad_dst or bad_src:
                 raise IndexError(f"edge_index has node ids outside [0, {self.num_nodes})")
+        self.deferred = mode == "deferred"
 
     @property
     def row32(self) -> torch.Tensor:

@@ -443,3 +443,35 @@ def test_forward_on_cpu_module_fails_loudly(G):
     m = G.GraphNet(**{"n_blocks": 1}).to("cpu")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(torch.zeros(4, 3), torch.zeros(4, 2), torch.zeros(2, 3, dtype=torch.long))
+
+
+def test_deferred_validation_poisons_the_output_and_raises_at_the_check(G):
+    """topology.set_validation("deferred"): no host sync in the build; a bad edge_index gives NaN on the device and
+    the IndexError of the synchronous mode when check_deferred() is called."""
+    from graphnet_classifier_amd import synthetic as S
+    from graphnet_classifier_amd import topology
+    batch = S.superpixel_like_graphs(2, seed=4)
+    torch.manual_seed(1)
+    m = G.GraphNet(**S.graphnet_kwargs(32, 1))
+    x, pos, ei = batch.x.to(DEV), batch.pos.to(DEV), batch.edge_index.to(DEV)
+    with torch.no_grad():
+        ref = m(x, pos, ei)
+    bad = ei.clone()
+    bad[0, 5] = batch.num_nodes + 3
+    with pytest.raises(IndexError):
+        with torch.no_grad():
+            m(x, pos, bad)  # default mode: raised by the build
+    topology.set_validation("deferred")
+    try:
+        topology.clear_topology_cache()
+        with torch.no_grad():
+            good = m(x, pos, ei)
+            poisoned = m(x, pos, bad)
+        assert torch.equal(good, ref)
+        assert bool(torch.isnan(poisoned).all())
+        with pytest.raises(IndexError):
+            topology.check_deferred()
+        topology.check_deferred()  # nothing pending any more
+    finally:
+        topology.set_validation("sync")
+        topology.clear_topology_cache()
