@@ -729,17 +729,22 @@ __global__ __launch_bounds__(FNT) void mlp_backward_fused_kernel(const gnc_mlp_d
     // (measured with the phase probe: 4.7k of a tile's 52k cycles)
     const int fle = fresh_lane();
     const int c4e = fle & 15, rse = fle >> 4;
-    if (b.dx && b.dx_add_grad_out) {
+    {  // all row pieces of both outputs out of the LDS tiles first, the residual added in registers, then the stores
+      f32x4 oz[NP], ox[NP];
       compiler_lds_barrier();
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
-        float* q = ta + (p * 4 + rse) * LDSW + c4e * 4;
-        *reinterpret_cast<f32x4*>(q) = *reinterpret_cast<const f32x4*>(q) + gres[p];
+        oz[p] = *reinterpret_cast<const f32x4*>(tb + (p * 4 + rse) * LDSW + c4e * 4);
+        ox[p] = *reinterpret_cast<const f32x4*>(ta + (p * 4 + rse) * LDSW + c4e * 4);
+      }
+      if (b.dx && b.dx_add_grad_out) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) ox[p] += gres[p];
       }
       compiler_lds_barrier();
+      if (b.dz[0]) store_row_pieces(oz, b.dz[0], d.out_dim[0], d.out_dim[0], row0, rows, c4e, rse);
+      if (b.dx) store_row_pieces(ox, b.dx + s0.wcol, b.ld_dx, s0.width, row0, rows, c4e, rse);
     }
-    if (b.dz[0]) store_staged_rows(tb, b.dz[0], d.out_dim[0], d.out_dim[0], row0, rows, c4e, rse);
-    if (b.dx) store_staged_rows(ta, b.dx + s0.wcol, b.ld_dx, s0.width, row0, rows, c4e, rse);
     compiler_lds_barrier();
     park(false);  // the rest of the next tile's rows (requested above, long landed) into the tiles this one has finished with
     BPROBE(7);  // collect loads + stores + park

@@ -587,16 +587,20 @@ __device__ __forceinline__ void store_staged_rows(const float* abuf, float* dst,
     }
     return;
   }
-  if (vec) {  // one piece at a time: 4 live registers, the asm stores keep the order
+  if (vec) {  // four pieces at a time: their LDS reads fly together (one round trip per group, not per piece)
     const uint32_t off = (uint32_t)(rs * ld + col) * 4u;
     if (col < width) {
       if (row0 + 4 * PIECES <= rows) {
         uint32_t r0b;
         const __amdgpu_buffer_rsrc_t w = full_tile_window(dst, row0, rows, ld, &r0b);
+        constexpr int GRP = PIECES < 4 ? PIECES : 4;
 #pragma unroll
-        for (int p = 0; p < PIECES; ++p) {
-          const f32x4 o = *reinterpret_cast<const f32x4*>(src + p * 4 * LDSW);
-          hidden_window_store_s<STREAM_OUT>(o, off + r0b, w, (uint32_t)(p * 16 * ld));
+        for (int p0 = 0; p0 < PIECES; p0 += GRP) {
+          f32x4 o[GRP];
+#pragma unroll
+          for (int p = 0; p < GRP; ++p) o[p] = *reinterpret_cast<const f32x4*>(src + (p0 + p) * 4 * LDSW);
+#pragma unroll
+          for (int p = 0; p < GRP; ++p) hidden_window_store_s<STREAM_OUT>(o[p], off + r0b, w, (uint32_t)((p0 + p) * 16 * ld));
         }
       } else {
 #pragma unroll
@@ -610,6 +614,37 @@ __device__ __forceinline__ void store_staged_rows(const float* abuf, float* dst,
       const int r = row0 + p * 4 + rs;
       store_row_piece(dst + (int64_t)(r < rows ? r : rows - 1) * ld, col, *reinterpret_cast<const f32x4*>(src + p * 4 * LDSW),
                       r < rows && col < width, width, false);
+    }
+  }
+}
+
+// Whole-row pieces that are already in registers (lane (rs, c4): 16 B of row p*4+rs for p < PIECES) -> columns
+// [0, width) of rows row0.. of dst: the register form of store_staged_rows.  Reading all pieces of a tile from LDS
+// first and issuing the stores back to back costs ~300 cycles per 32-row tile where the one-piece-at-a-time form
+// (LDS read, wait, s_nop, store, eight times) measured ~1,200 in the fused K8 kernel's phase probe.
+template <int PIECES = NP, bool STREAM_OUT = false>
+__device__ __forceinline__ void store_row_pieces(const f32x4 (&v)[PIECES], float* dst, int ld, int width, int row0, int rows,
+                                                 int c4, int rs) {
+  const int col = c4 * 4;
+  const bool vec = (width % 4 == 0) && (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0);
+  if (vec) {
+    const uint32_t off = (uint32_t)(rs * ld + col) * 4u;
+    if (col < width) {
+      if (row0 + 4 * PIECES <= rows) {
+        uint32_t r0b;
+        const __amdgpu_buffer_rsrc_t w = full_tile_window(dst, row0, rows, ld, &r0b);
+#pragma unroll
+        for (int p = 0; p < PIECES; ++p) hidden_window_store_s<STREAM_OUT>(v[p], off + r0b, w, (uint32_t)(p * 16 * ld));
+      } else {
+#pragma unroll
+        for (int p = 0; p < PIECES; ++p) hidden_window_store(v[p], off, row_window(dst, row0 + 4 * p, rows, ld));
+      }
+    }
+  } else {
+#pragma unroll
+    for (int p = 0; p < PIECES; ++p) {
+      const int r = row0 + p * 4 + rs;
+      store_row_piece(dst + (int64_t)(r < rows ? r : rows - 1) * ld, col, v[p], r < rows && col < width, width, false);
     }
   }
 }
