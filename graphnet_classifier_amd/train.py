@@ -179,8 +179,6 @@ def train(model, dataset, epochs, patience=5, output_path='weights', start_weigh
     flat = FlatParameters(model)
     optimizer = FusedAdam(flat, lr=lr)                                                 # :9
     criterion = nn.CrossEntropyLoss()                                                  # :10
-    best_loss = float('inf')
-    patience_counter = 0
 
     os.makedirs(output_path, exist_ok=True)                                            # :18
     print(f"Training model in {output_path}")
@@ -196,9 +194,26 @@ def train(model, dataset, epochs, patience=5, output_path='weights', start_weigh
         torch.save({k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, path)
 
     loss_sum = torch.zeros((), dtype=torch.float64, device=dev)
+    history = []
+    # The whole loop runs on a side stream.  A hipGraph capture that follows eager autograd steps issued on the
+    # legacy default stream takes the HIP runtime down at hipStreamEndCapture (reproduced: tools/repro_capture2.py,
+    # MODE=eager_first segfaults, MODE=eager_side does not); PyTorch's whole-network capture recipe asks for a
+    # side-stream warm-up for the same reason.  Nothing here depends on the default stream.
+    run_stream = torch.cuda.Stream(device=dev)
+    run_stream.wait_stream(torch.cuda.current_stream(dev))
+    try:
+        with torch.cuda.stream(run_stream):
+            return _train_loop(model, dataset, epochs, patience, output_path, dev, optimizer, criterion, capture, log_path, save,
+                               loss_sum, history)
+    finally:
+        torch.cuda.current_stream(dev).wait_stream(run_stream)
+
+
+def _train_loop(model, dataset, epochs, patience, output_path, dev, optimizer, criterion, capture, log_path, save, loss_sum, history):
+    best_loss = float('inf')
+    patience_counter = 0
     captured: CapturedTrainStep | None = None
     prev_sample = None
-    history = []
     for epoch in range(epochs):
         checkpoint1 = time.time()
         loss_sum.zero_()
