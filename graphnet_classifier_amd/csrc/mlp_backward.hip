@@ -824,11 +824,10 @@ __device__ __forceinline__ void mma_transposed_chunk(f32x16 (&dst)[TO], const f3
   }
 }
 
-template <int HT>
-__global__ __launch_bounds__(256) void mlp_backward_stream_kernel(const gnc_mlp_desc_t d, const BwdArgs b, const BwdPlan pl,
-                                                                  const int num_tiles) {
+template <int HT, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void mlp_backward_stream_kernel(const gnc_mlp_desc_t d, const BwdArgs b, const BwdPlan pl,
+                                                                         const int num_tiles) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int WAVES = 4;
   constexpr int NT = WAVES * 64;
   constexpr int CH = HT * 32 * LDSW;
   constexpr int PSTRIDE = HT * 32;
@@ -840,10 +839,6 @@ __global__ __launch_bounds__(256) void mlp_backward_stream_kernel(const gnc_mlp_
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 31;
   const int h = lane >> 5;
-  const int c4 = lane & 15;
-  const int rs = lane >> 4;
-  const int wc4 = tid & 15;
-  const int wr0 = tid >> 4;
   const int L = d.num_linear;
   const int out_dim = d.out_dim[L - 1];
   const int rows = (int)d.rows;
@@ -854,6 +849,8 @@ __global__ __launch_bounds__(256) void mlp_backward_stream_kernel(const gnc_mlp_
   stage_params<NT>(pbuf, d, PSTRIDE, tid);
 
   auto wload = [&](f32x4 (&wr)[NW], int q) {
+    const int ftid = wave * 64 + fresh_lane();  // roles recomputed per use (see fresh_lane): nothing lane-derived is carried
+    const int wc4 = ftid & 15, wr0 = ftid >> 4;
     const int layer = pl.wc[q].layer;
     const float* W = d.weight[layer];
     const int ldw = ldw_of(d, layer);
@@ -873,16 +870,20 @@ __global__ __launch_bounds__(256) void mlp_backward_stream_kernel(const gnc_mlp_
     }
   };
   auto wstore = [&](const f32x4 (&wr)[NW], float* buf) {
+    const int ftid = wave * 64 + fresh_lane();
+    const int wc4 = ftid & 15, wr0 = ftid >> 4;
 #pragma unroll
     for (int p = 0; p < NW; ++p) *reinterpret_cast<f32x4*>(buf + (p * RPP + wr0) * LDSW + wc4 * 4) = wr[p];
   };
   auto load_idx = [&](int row0, int s) -> int {
-    int r = row0 + (lane & 31);
+    int r = row0 + (fresh_lane() & 31);
     r = r < rows ? r : rows - 1;
     const int32_t* ip = d.seg[s].index;
     return ip ? ip[r] : r;
   };
   auto load_rows = [&](f32x4 (&pre)[NP], const float* base, int ld, int c0, int idxv) {
+    const int fl = fresh_lane();
+    const int c4 = fl & 15, rs = fl >> 4;
     const int col = c0 + c4 * 4 < ld ? c0 + c4 * 4 : 0;
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
@@ -892,18 +893,27 @@ __global__ __launch_bounds__(256) void mlp_backward_stream_kernel(const gnc_mlp_
   };
   auto stage = [&](const f32x4 (&pre)[NP], int c0, int width) {
     compiler_lds_barrier();
+    const int fl = fresh_lane();
+    const int c4 = fl & 15, rs = fl >> 4;
     const int c = c0 + c4 * 4;
+    if (c0 + KC <= width) {  // full slab: nothing to mask
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      f32x4 v = pre[p];
-      v.x = c + 0 < width ? v.x : 0.f; v.y = c + 1 < width ? v.y : 0.f;
-      v.z = c + 2 < width ? v.z : 0.f; v.w = c + 3 < width ? v.w : 0.f;
-      *reinterpret_cast<f32x4*>(abuf + (p * 4 + rs) * LDSW + c4 * 4) = v;
+      for (int p = 0; p < NP; ++p) *reinterpret_cast<f32x4*>(abuf + (p * 4 + rs) * LDSW + c4 * 4) = pre[p];
+    } else {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        f32x4 v = pre[p];
+        v.x = c + 0 < width ? v.x : 0.f; v.y = c + 1 < width ? v.y : 0.f;
+        v.z = c + 2 < width ? v.z : 0.f; v.w = c + 3 < width ? v.w : 0.f;
+        *reinterpret_cast<f32x4*>(abuf + (p * 4 + rs) * LDSW + c4 * 4) = v;
+      }
     }
     compiler_lds_barrier();
   };
   // 64 columns [64*cc, +64) of `acc` -> rows of dst (columns < width)
   auto emit_chunk = [&](float* dst, int ld, int width, int row0, int cc) {
+    const int fl = fresh_lane();
+    const int c4 = fl & 15, rs = fl >> 4;
     compiler_lds_barrier();
     store_staged_rows(abuf, dst + cc * KC, ld, width - cc * KC < KC ? width - cc * KC : KC, row0, rows, c4, rs);
     compiler_lds_barrier();
@@ -1022,13 +1032,26 @@ __global__ __launch_bounds__(256) void mlp_backward_stream_kernel(const gnc_mlp_
       }
     }
 
-    // ------------------------------------------------------------------ grad_out tile, LayerNorm backward
+    // ------------------------------------------------------------------ LayerNorm recompute FIRST (the last hidden
+    // activations die with it), THEN the grad_out tile: never more than two accumulator sets live
+    f32x16 y[HT];
+    if (d.ln_gamma) {
+      init_bias<HT>(y, pbuf + (L - 1) * PSTRIDE, h);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        if (c * KC < d.in_dim[L - 1]) {
+          prefetch_next_chunk();
+          mma_chunk_from_regs<HT, HT>(y, hid, cur_chunk(), c, d.in_dim[L - 1], i, h);
+          publish_next_chunk();
+        }
+      }
+    }
     f32x16 g[HT];
 #pragma unroll
     for (int cc = 0; cc < NCH; ++cc) {
       if (cc * KC < out_dim) {
         f32x4 pre[NP];
-        int r = row0 + (lane & 31);
+        int r = row0 + (fresh_lane() & 31);
         r = r < rows ? r : rows - 1;
         load_rows(pre, b.grad_out, b.ld_grad_out, cc * KC, r);
         stage(pre, cc * KC, out_dim);
@@ -1052,16 +1075,6 @@ __global__ __launch_bounds__(256) void mlp_backward_stream_kernel(const gnc_mlp_
       }
     }
     if (d.ln_gamma) {
-      f32x16 y[HT];
-      init_bias<HT>(y, pbuf + (L - 1) * PSTRIDE, h);
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        if (c * KC < d.in_dim[L - 1]) {
-          prefetch_next_chunk();
-          mma_chunk_from_regs<HT, HT>(y, hid, cur_chunk(), c, d.in_dim[L - 1], i, h);
-          publish_next_chunk();
-        }
-      }
       layer_norm_backward_tiles<HT>(y, g, pbuf + L * PSTRIDE, out_dim, d.ln_eps, h);
       emit(y, b.yhat, out_dim, out_dim, row0);
     } else {
@@ -1102,9 +1115,10 @@ __global__ __launch_bounds__(256) void mlp_backward_stream_kernel(const gnc_mlp_
         chunk_to_lds<2, 0>(dxs, abuf, i, h);
         // columns c0 .. c0+63 of segment s -> dx[:, wcol_s + c0 ...]
         {
+          const int fl = fresh_lane();
           compiler_lds_barrier();
           store_staged_rows(abuf, b.dx + d.seg[s].wcol + c0, b.ld_dx, d.seg[s].width - c0 < KC ? d.seg[s].width - c0 : KC, row0,
-                            rows, c4, rs);
+                            rows, fl & 15, fl >> 4);
           compiler_lds_barrier();
         }
       }
@@ -1380,21 +1394,21 @@ bool bwd_stream_plan(const gnc_mlp_desc_t& d, bool want_dx, BwdPlan* pl, int* T_
   return true;
 }
 
-template <int HT>
+template <int HT, int WAVES>
 int launch_bwd_stream(const gnc_mlp_desc_t& d, const BwdArgs& b, const BwdPlan& pl, hipStream_t stream) {
-  const size_t smem = ((size_t)2 * HT * 32 * LDSW + (size_t)(d.num_linear + 2) * HT * 32 + (size_t)4 * RPW * LDSW) * sizeof(float);
+  const size_t smem = ((size_t)2 * HT * 32 * LDSW + (size_t)(d.num_linear + 2) * HT * 32 + (size_t)WAVES * RPW * LDSW) * sizeof(float);
   if (smem > 160 * 1024) { gnc::set_error("mlp_backward_stream: LDS budget exceeded"); return GNC_ERR_UNSUPPORTED; }
   static bool attr_set = false;
   if (!attr_set) {
-    int rc = gnc::check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_backward_stream_kernel<HT>),
+    int rc = gnc::check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_backward_stream_kernel<HT, WAVES>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
                             "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc) return rc;
     attr_set = true;
   }
-  const int64_t num_tiles = gnc::ceil_div(d.rows, (int64_t)4 * RPW);
+  const int64_t num_tiles = gnc::ceil_div(d.rows, (int64_t)WAVES * RPW);
   const int64_t grid = num_tiles < gnc::num_cu() ? num_tiles : gnc::num_cu();
-  mlp_backward_stream_kernel<HT><<<dim3((unsigned)grid), dim3(256), smem, stream>>>(d, b, pl, (int)num_tiles);
+  mlp_backward_stream_kernel<HT, WAVES><<<dim3((unsigned)grid), dim3(WAVES * 64), smem, stream>>>(d, b, pl, (int)num_tiles);
   return gnc::check_launch("mlp_backward_stream_kernel");
 }
 
@@ -1533,10 +1547,11 @@ extern "C" int gnc_mlp_backward_f32(const gnc_mlp_bwd_desc_t* bd, void* stream_)
   if (stream16) return launch_bwd_stream16(d, b, (hipStream_t)stream_);
   if (!resident) {
     hipStream_t st = (hipStream_t)stream_;
+    static const bool w4 = getenv("GNC_BWD_STREAM_W4") != nullptr;  // A/B: the 4-wave (one per SIMD, 512 registers) form at 128
     switch (T) {
-      case 1: return launch_bwd_stream<1>(d, b, pl, st);
-      case 2: return launch_bwd_stream<2>(d, b, pl, st);
-      default: return launch_bwd_stream<4>(d, b, pl, st);
+      case 1: return launch_bwd_stream<1, 4>(d, b, pl, st);
+      case 2: return launch_bwd_stream<2, 4>(d, b, pl, st);
+      default: return w4 ? launch_bwd_stream<4, 4>(d, b, pl, st) : launch_bwd_stream<4, 8>(d, b, pl, st);
     }
   }
   const int total_chunks = nmm + (L - 1);
