@@ -767,7 +767,7 @@ int launch_resident(const gnc_mlp_desc_t& d, int T, bool narrow_out, hipStream_t
 int launch_stream(const gnc_mlp_desc_t& d, int T, bool narrow_out, hipStream_t stream, bool* launched,
                   bool probe_only = false);
 // widths 129..256 on v_mfma_f32_16x16x4_f32, 16 rows per wave (mlp_stream16.hip); same contract
-int launch_stream16(const gnc_mlp_desc_t& d, hipStream_t stream, bool* launched);
+int launch_stream16(const gnc_mlp_desc_t& d, hipStream_t stream, bool* launched, bool probe_only = false);
 // K8 data kernel for widths 129..256 on 16-row tiles (mlp_backward16.hip): shape query / launch
 bool bwd_stream16_supported(const gnc_mlp_desc_t& d, bool want_dx);
 int launch_bwd_stream16(const gnc_mlp_desc_t& d, const BwdArgs& b, hipStream_t stream);

@@ -277,6 +277,10 @@ extern "C" int gnc_mlp_agg_supported(const gnc_mlp_desc_t* desc) {
     rc = launch_stream(probe, T, narrow_out, nullptr, &ok, true);
     if (rc) return rc;
   }
+  if (!ok && T == 8) {  // 129..256 features: the 16-row streaming kernel
+    rc = launch_stream16(probe, nullptr, &ok, true);
+    if (rc) return rc;
+  }
   if (!ok) {
     gnc::set_error("gnc_mlp_agg_supported: needs the weights-resident W-split shape (1 MATMUL + 2 ADD segments, residual = "
                    "the MATMUL segment, widths 33..64) or a 65..128-wide description of the streaming kernel");
@@ -299,7 +303,7 @@ extern "C" int gnc_mlp_forward_f32(const gnc_mlp_desc_t* desc, void* stream_) {
   bool launched = false;  // weights-resident variant first (decides by LDS fit)
   rc = launch_resident(*desc, T, narrow_out, stream, &launched);
   if (rc || launched) return rc;
-  if (desc->agg_out && T != 4) {
+  if (desc->agg_out && T != 4 && T != 8) {
     gnc::set_error("gnc_mlp_forward_f32: the fused aggregation epilogue is not available for this description "
                    "(gnc_mlp_agg_supported)");
     return GNC_ERR_UNSUPPORTED;
@@ -308,6 +312,11 @@ extern "C" int gnc_mlp_forward_f32(const gnc_mlp_desc_t* desc, void* stream_) {
   if (T == 8 || (T == 4 && s16_128 && !desc->agg_out)) {  // 129..256 features: 16-row tiles on the 16x16x4 MFMA
     rc = launch_stream16(*desc, stream, &launched);
     if (rc || launched) return rc;
+    if (desc->agg_out && T == 8) {
+      gnc::set_error("gnc_mlp_forward_f32: the fused aggregation epilogue is not available for this description "
+                     "(gnc_mlp_agg_supported)");
+      return GNC_ERR_UNSUPPORTED;
+    }
   }
   rc = launch_stream(*desc, T, narrow_out, stream, &launched);  // wide layers: double-buffered weight stream
   if (rc || launched) return rc;

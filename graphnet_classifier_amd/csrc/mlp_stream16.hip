@@ -29,7 +29,11 @@ struct Plan16 {
 };
 
 // NTH / NTO: 16-feature tiles of the hidden / output width (4, 8 or 16; NTO may be 1 for the decoder)
-template <int NTH, int NTO, bool DBUF>
+// AGG: fused aggregation epilogue (gnc_mlp_desc_t.agg_out, see mlp_resident.hip / mlp_stream.hip): every wave owns a
+// CONTIGUOUS range of 16-row wave tiles and carries the running sum of the destination in progress, one register per 64
+// output columns; the workgroup still steps through the weight chunks in lockstep, so waves whose range is one tile
+// shorter run a last iteration on a tile past the table's end (loads return zeros / clamped rows, stores are dropped).
+template <int NTH, int NTO, bool DBUF, bool AGG = false>
 __global__ __launch_bounds__(NT16) void mlp_stream16_kernel(const gnc_mlp_desc_t d, const Plan16 pl, const int num_tiles) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int NTW = NTH > NTO ? NTH : NTO;
@@ -93,10 +97,27 @@ __global__ __launch_bounds__(NT16) void mlp_stream16_kernel(const gnc_mlp_desc_t
 #pragma unroll
     for (int p = 0; p < NW; ++p) *reinterpret_cast<f32x4*>(buf + (p * RPP + wr0) * LDSW + wc4 * 4) = wr[p];
   };
-  const int last_tile = num_tiles - 1;
-  auto load_idx = [&](int tile, int s) -> int {
-    const int tc = tile < last_tile ? tile : last_tile;
-    int r = (tc * W16 + wave) * R16 + (lane & 15);
+  // Tile schedule in WAVE tiles (16 rows each).  Default: workgroup tile t = blockIdx.x + k * gridDim.x, the wave takes
+  // wave tile t * 8 + wave.  AGG: one contiguous range per wave.  `iters` is workgroup-uniform.
+  const int num_wtiles = (rows + R16 - 1) / R16;
+  const int last_wt = num_wtiles - 1;
+  const int gwave = (int)blockIdx.x * W16 + wave;
+  int agg_t0 = 0, agg_cnt = 0, iters;
+  if constexpr (AGG) {
+    const int tw = (int)gridDim.x * W16, qq = num_wtiles / tw, rem = num_wtiles - qq * tw;
+    agg_t0 = gwave * qq + (gwave < rem ? gwave : rem);
+    agg_cnt = qq + (gwave < rem ? 1 : 0);
+    iters = qq + ((int)blockIdx.x * W16 < rem ? 1 : 0);
+  } else {
+    iters = (num_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  }
+  auto wtile_of = [&](int k) -> int {  // wave tile of iteration k (>= num_wtiles: past the end)
+    if constexpr (AGG) return k < agg_cnt ? agg_t0 + k : num_wtiles;
+    return ((int)blockIdx.x + k * (int)gridDim.x) * W16 + wave;
+  };
+  auto load_idx = [&](int wt_, int s) -> int {
+    const int tc = wt_ < last_wt ? wt_ : last_wt;
+    int r = tc * R16 + (lane & 15);
     r = r < rows ? r : rows - 1;
     const int32_t* ip = d.seg[s].index;
     return ip ? ip[r] : r;
@@ -108,7 +129,7 @@ __global__ __launch_bounds__(NT16) void mlp_stream16_kernel(const gnc_mlp_desc_t
     const int ld = d.seg[s].ld;
     const int col = c0 + c4 * 4 < ld ? c0 + c4 * 4 : 0;
     if (d.seg[s].index == nullptr) {  // row-ordered: window at the tile's first row
-      load_tile_rows<false, NP16>(pre, base, ld, ((int64_t)tile_of * W16 + wave) * R16, rows, (uint32_t)(rs * ld + col) * 4u);
+      load_tile_rows<false, NP16>(pre, base, ld, (int64_t)tile_of * R16, rows, (uint32_t)(rs * ld + col) * 4u);
     } else {
       const int64_t tbytes = d.seg[s].table_rows * (int64_t)ld * 4;
       if (tbytes > 0 && tbytes <= 0xffffffffll) {
@@ -150,11 +171,12 @@ __global__ __launch_bounds__(NT16) void mlp_stream16_kernel(const gnc_mlp_desc_t
   };
 
   int ids[GNC_MAX_SEGMENTS], ids_next[GNC_MAX_SEGMENTS];
-  int tile = blockIdx.x;
+  int kit = 0;
+  int tile = wtile_of(0);  // the wave tile in progress
 #pragma unroll
   for (int s = 0; s < GNC_MAX_SEGMENTS; ++s) {
     ids[s] = s < d.num_segments ? load_idx(tile, s) : 0;
-    ids_next[s] = s < d.num_segments ? load_idx(tile + (int)gridDim.x, s) : 0;
+    ids_next[s] = s < d.num_segments ? load_idx(wtile_of(1), s) : 0;
   }
   auto id_of = [&](int s) {
     int v = 0;
@@ -182,9 +204,24 @@ __global__ __launch_bounds__(NT16) void mlp_stream16_kernel(const gnc_mlp_desc_t
   };
   auto cur_w = [&]() -> const float* { return wbuf + (DBUF ? (gq & 1) : 0) * CH; };
 
-  while (tile < num_tiles) {
-    const int row0 = (tile * W16 + wave) * R16;
-    const int ntile = tile + gridDim.x;
+  // fused aggregation state (AGG): destination ids of the tile's rows, running sums (lane = feature, per 64 columns)
+  auto agg_ids = [&](int wt_) -> int {
+    int r = wt_ * R16 + (lane & 15);
+    r = r < rows ? r : rows - 1;
+    return d.agg_index[r];
+  };
+  int aid = 0, aid_next = 0;
+  float agg_acc[AGG ? NCHO : 1];
+#pragma unroll
+  for (int c = 0; c < (AGG ? NCHO : 1); ++c) agg_acc[c] = 0.f;
+  int agg_cur = -1, agg_first_dst = -1;  // wave-uniform
+  bool agg_first = true;
+  if constexpr (AGG) aid = agg_ids(tile);
+
+  while (kit < iters) {
+    const int row0 = tile * R16;
+    const int ntile = wtile_of(kit + 1);
+    if constexpr (AGG) aid_next = agg_ids(ntile);
     int q = 0;
 
     // ------------------------------------------------------------------ first Linear
@@ -199,7 +236,7 @@ __global__ __launch_bounds__(NT16) void mlp_stream16_kernel(const gnc_mlp_desc_t
 #pragma unroll
         for (int k = 0; k < GNC_MAX_SEGMENTS; ++k) {
           ids[k] = ids_next[k];
-          if (k < d.num_segments) ids_next[k] = load_idx(ntile + (int)gridDim.x, k);
+          if (k < d.num_segments) ids_next[k] = load_idx(wtile_of(kit + 2), k);
         }
       }
       load_rows(cur, pl.step[nst].seg, pl.step[nst].c0, id_of(pl.step[nst].seg), wrap ? ntile : tile);
@@ -283,16 +320,81 @@ __global__ __launch_bounds__(NT16) void mlp_stream16_kernel(const gnc_mlp_desc_t
         for (int cb = 0; cb < 4; ++cb)
           if (4 * cc + cb < NTO) *reinterpret_cast<f32x4*>(abuf + i * LDSW + 16 * cb + 4 * g) = o[4 * cc + cb < NTO ? 4 * cc + cb : 0];
         compiler_lds_barrier();
-        store_staged_rows<NP16, true>(abuf, d.out + cc * KC, d.ld_out, out_dim - cc * KC < KC ? out_dim - cc * KC : KC, row0, rows, c4,
-                                rs, d.residual ? d.residual + cc * KC : nullptr, d.ld_residual);
+        if constexpr (AGG) {
+          // the residual joins the staged tile first (whole rows), so that the LDS tile holds the FINAL rows that are
+          // both stored and summed per destination
+          const int wcc = out_dim - cc * KC < KC ? out_dim - cc * KC : KC;
+          if (d.residual) {
+            f32x4 rv[NP16];
+            load_tile_rows<false, NP16>(rv, d.residual + cc * KC, d.ld_residual, row0, rows,
+                                        (uint32_t)(rs * d.ld_residual + (c4 * 4 < wcc ? c4 * 4 : 0)) * 4u);
+#pragma unroll
+            for (int p = 0; p < NP16; ++p) {
+              float* qp = abuf + (p * 4 + rs) * LDSW + c4 * 4;
+              *reinterpret_cast<f32x4*>(qp) = *reinterpret_cast<const f32x4*>(qp) + rv[p];
+            }
+            compiler_lds_barrier();
+          }
+          store_staged_rows<NP16, true>(abuf, d.out + cc * KC, d.ld_out, wcc, row0, rows, c4, rs);
+          // walk of this slab's 16 row values (lane = column of the slab): wave-uniform control (a ballot of "row starts
+          // a new destination"), one add per row.  Every slab replays the walk from the tile's starting state; the state
+          // is committed after the last slab.
+          float rowv[R16];
+#pragma unroll
+          for (int r = 0; r < R16; ++r) rowv[r] = abuf[r * LDSW + (fle & 63)];
+          const int valid = rows - row0 < R16 ? (rows - row0 > 0 ? rows - row0 : 0) : R16;
+          int prv = __shfl_up(aid, 1, 64);
+          prv = (fle & 63) == 0 ? agg_cur : prv;
+          const unsigned vmask = valid >= R16 ? 0xffffu : ((1u << valid) - 1u);
+          const unsigned bnd = (unsigned)(__ballot(aid != prv) & 0xffffull) & vmask;
+          int w_cur = agg_cur, w_first_dst = agg_first_dst;
+          bool w_first = agg_first;
+          float acc = agg_acc[cc];
+#pragma unroll
+          for (int r = 0; r < R16; ++r) {
+            if (r < valid) {
+              if ((bnd >> r) & 1u) {
+                if (w_cur >= 0) {
+                  if (w_first) {
+                    w_first = false;
+                    w_first_dst = w_cur;
+                  } else if (cc * KC + (fle & 63) < out_dim) {
+                    float* dstp = d.agg_out + (int64_t)w_cur * d.ld_agg;
+                    asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2\n\ts_nop 0" ::"v"((cc * KC + (fle & 63)) * 4), "v"(acc), "s"(dstp) : "memory");
+                  }
+                }
+                w_cur = __builtin_amdgcn_readlane(aid, r);
+                acc = 0.f;
+              }
+              acc += rowv[r];
+            }
+          }
+          agg_acc[cc] = acc;
+          if (cc == NCHO - 1 || (cc + 1) * KC >= out_dim) {  // last slab of the tile: commit the walk's state
+            agg_cur = w_cur;
+            agg_first = w_first;
+            agg_first_dst = w_first_dst;
+          }
+        } else {
+          store_staged_rows<NP16, true>(abuf, d.out + cc * KC, d.ld_out, out_dim - cc * KC < KC ? out_dim - cc * KC : KC, row0, rows, c4,
+                                        rs, d.residual ? d.residual + cc * KC : nullptr, d.ld_residual);
+        }
       }
     }
+    if constexpr (AGG) aid = aid_next;
     compiler_lds_barrier();
     tile = ntile;
+    ++kit;
+  }
+  if constexpr (AGG) {  // the range's first and last destination (possibly the same, possibly none) go to the fix-up
+    if (lane == 0) {
+      d.agg_fix[2 * gwave] = agg_first ? agg_cur : agg_first_dst;
+      d.agg_fix[2 * gwave + 1] = agg_cur;
+    }
   }
 }
 
-template <int NTH, int NTO>
+template <int NTH, int NTO, bool AGG = false>
 int launch16(const gnc_mlp_desc_t& d, const Plan16& pl, hipStream_t stream) {
   constexpr int NTW = NTH > NTO ? NTH : NTO;
   constexpr bool DBUF = NTW <= 8;
@@ -304,15 +406,16 @@ int launch16(const gnc_mlp_desc_t& d, const Plan16& pl, hipStream_t stream) {
   }
   static bool attr_set = false;
   if (!attr_set) {
-    int rc = gnc::check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_stream16_kernel<NTH, NTO, DBUF>),
+    int rc = gnc::check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_stream16_kernel<NTH, NTO, DBUF, AGG>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
                             "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc) return rc;
     attr_set = true;
   }
   const int64_t num_tiles = gnc::ceil_div(d.rows, (int64_t)W16 * R16);
-  const int64_t grid = num_tiles < gnc::num_cu() ? num_tiles : gnc::num_cu();
-  mlp_stream16_kernel<NTH, NTO, DBUF><<<dim3((unsigned)grid), dim3(NT16), smem, stream>>>(d, pl, (int)num_tiles);
+  int64_t grid = num_tiles < gnc::num_cu() ? num_tiles : gnc::num_cu();
+  if constexpr (AGG) grid = gnc::num_cu();  // agg_fix has two entries for every wave of the full grid (8 waves per workgroup)
+  mlp_stream16_kernel<NTH, NTO, DBUF, AGG><<<dim3((unsigned)grid), dim3(NT16), smem, stream>>>(d, pl, (int)num_tiles);
   return gnc::check_launch("mlp_stream16_kernel");
 }
 
@@ -320,7 +423,7 @@ bool al16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; 
 
 }  // namespace
 
-int gnc_mlp::launch_stream16(const gnc_mlp_desc_t& d, hipStream_t stream, bool* launched) {
+int gnc_mlp::launch_stream16(const gnc_mlp_desc_t& d, hipStream_t stream, bool* launched, bool probe_only) {
   *launched = false;
   static const bool disabled = getenv("GNC_MLP_NO_STREAM16") != nullptr;  // A/B switch for benchmarking
   if (disabled || d.rows >= INT32_MAX) return GNC_OK;
@@ -355,7 +458,14 @@ int gnc_mlp::launch_stream16(const gnc_mlp_desc_t& d, hipStream_t stream, bool* 
       if (pl.num_wchunks >= MAX_WCHUNKS16) return GNC_OK;
       pl.wc[pl.num_wchunks++] = {(short)l, (short)(c * KC), (short)d.in_dim[l], 0};
     }
+  if (d.agg_out) {  // aggregation epilogue: the 256-wide instance only (129..256 output features), rows < 2^31 / 16
+    if (!(od > 128 && L > 1) || !d.agg_index || !d.agg_fix || d.ld_agg < od) return GNC_OK;
+    *launched = true;
+    if (probe_only) return GNC_OK;
+    return launch16<16, 16, true>(d, pl, stream);
+  }
   *launched = true;
+  if (probe_only) return GNC_OK;
   if (H <= 128 && od <= 128) {
     if (od <= 16 && L > 1) return launch16<8, 1>(d, pl, stream);
     return launch16<8, 8>(d, pl, stream);

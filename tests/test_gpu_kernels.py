@@ -290,13 +290,13 @@ def test_mlp_additive_segments_equal_concat_form(native, d):
     assert max_abs(y.cpu(), ref) < 1e-5
 
 
-@pytest.mark.parametrize("d", [64, 128])
+@pytest.mark.parametrize("d", [64, 128, 256])
 @pytest.mark.parametrize("n,e,hot", [(211, 1500, 0), (40, 33, 0), (5000, 70001, 0), (3000, 90000, 30000), (7, 4096, 0)])
 def test_fused_aggregation_epilogue_bit_equals_k1(native, n, e, hot, d):
     """the edge kernel's segmented-sum epilogue (gnc_mlp_desc_t.agg_out) + gnc_agg_fixup_f32 give,
     bit for bit, what K1 gives on the stored rows: empty destinations, tails, more waves than tiles, one
     destination spanning many waves' ranges (`hot` rows of destination 5).  d = 64: weights-resident kernel,
-    d = 128: streaming kernel (two 64-column chunks per tile)."""
+    d = 128: streaming kernel (two 64-column chunks per tile), d = 256: 16-row streaming kernel (four slabs per tile)."""
     rng = np.random.default_rng(n + e + d)
     sd = _mlp_sd(rng, 3 * d, d, d, 2, True)
     dst = rng.integers(0, n, size=e)
@@ -320,9 +320,9 @@ def test_fused_aggregation_epilogue_bit_equals_k1(native, n, e, hot, d):
     y0 = native.mlp_forward(segs, ws, bs, ln=ln, residual=ea, modes=modes)
     y, agg = native.mlp_forward(segs, ws, bs, ln=ln, residual=ea, modes=modes,
                                 aggregate=(torch.from_numpy(dst).to(DEV), rowptr, n))
-    if agg is None and (os.environ.get("GNC_MLP_NO_RESIDENT") or os.environ.get("GNC_MLP_NO_STREAM2")):
+    if agg is None and (os.environ.get("GNC_MLP_NO_RESIDENT") or os.environ.get("GNC_MLP_NO_STREAM2") or os.environ.get("GNC_MLP_NO_STREAM16")):
         pytest.skip("the kernel that carries the epilogue at this width is switched off by an A/B variable")
-    assert agg is not None, "the W-split edge shape at widths 64 and 128 must take the fused epilogue"
+    assert agg is not None, "the W-split edge shape at widths 64, 128 and 256 must take the fused epilogue"
     assert torch.equal(y, y0)
     ref = native.scatter_sum_csr(y, rowptr, None, n)
     assert torch.equal(agg, ref)
@@ -330,7 +330,7 @@ def test_fused_aggregation_epilogue_bit_equals_k1(native, n, e, hot, d):
     assert torch.equal(agg.cpu(), O.scatter_sum(y.cpu(), torch.from_numpy(dst).long(), dim_size=n))
 
 
-@pytest.mark.parametrize("d", [64, 128])
+@pytest.mark.parametrize("d", [64, 128, 256])
 def test_fused_aggregation_random_shapes(native, d):
     """Twelve random (nodes, edges, degree law) draws per width, including power-law degrees, all edges on one
     destination and row counts around multiples of the tile and of the grid's wave count."""
@@ -360,7 +360,7 @@ def test_fused_aggregation_random_shapes(native, d):
         dst_t = torch.from_numpy(dst).to(DEV)
         y, agg = native.mlp_forward([(ps, torch.from_numpy(src).to(DEV)), (pd, dst_t), (ea, None)], ws, bs, ln=ln, residual=ea,
                                     modes=modes, aggregate=(dst_t, rowptr, n))
-        if agg is None and (os.environ.get("GNC_MLP_NO_RESIDENT") or os.environ.get("GNC_MLP_NO_STREAM2")):
+        if agg is None and (os.environ.get("GNC_MLP_NO_RESIDENT") or os.environ.get("GNC_MLP_NO_STREAM2") or os.environ.get("GNC_MLP_NO_STREAM16")):
             pytest.skip("the kernel that carries the epilogue at this width is switched off by an A/B variable")
         assert agg is not None
         assert torch.equal(agg, native.scatter_sum_csr(y, rowptr, None, n)), (n, e, k)

@@ -97,8 +97,8 @@ def test_edge_processor_wsplit_and_aggregation_beyond_4gib(native, width):
     y, agg = native.mlp_forward([(ps, src), (pd, dst), (ea, None)], [w0[:, 2 * width:]] + ws[1:], bs, ln=ln, residual=ea,
                                 modes=modes, aggregate=(dst, rowptr, n))
     k1 = native.scatter_sum_csr(y, rowptr, None, n)
-    if agg is not None:
-        assert torch.equal(agg, k1)
+    assert agg is not None, "the W-split edge shape carries the aggregation epilogue at every width class"
+    assert torch.equal(agg, k1)
     idx, edge = _sample_rows(e, width)
     di = idx.to(DEV)
     cat = torch.cat([x[src[di].long()], x[dst[di].long()], ea[di]], -1).cpu()
