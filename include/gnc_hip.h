@@ -183,8 +183,9 @@ typedef struct gnc_mlp_desc {
    *   - destinations cut by a range boundary are not written either: the kernel lists them (and -1 for
    *     idle waves) in agg_fix [gnc_mlp_agg_fix_len()] int32, and gnc_agg_fixup_f32 recomputes exactly
    *     those rows from `out` through the row pointers afterwards (same stream).
-   * Served by the weights-resident kernel only (out_dim <= 64, residual = last MATMUL segment or none):
-   * ask gnc_mlp_agg_supported(); gnc_mlp_forward_f32 returns GNC_ERR_UNSUPPORTED otherwise. */
+   * Served by the weights-resident kernel (widths <= 64), the 32-row streaming kernel (65..128) and the 16-row
+   * streaming kernel (129..256, num_linear > 1): ask gnc_mlp_agg_supported(); gnc_mlp_forward_f32 returns
+   * GNC_ERR_UNSUPPORTED otherwise. */
   float* agg_out;           /* [*, ld_agg] or NULL */
   int32_t ld_agg;
   const int32_t* agg_index; /* [rows] destination of each output row */
