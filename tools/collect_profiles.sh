@@ -31,3 +31,13 @@ for W in $WORKLOADS; do
   rm -rf $OUT/${TAG}_pmc_${W}_sq $OUT/${TAG}_pmc_${W}_fetch $OUT/${TAG}_pmc_${W}_write $OUT/${TAG}_prof_$W
 done
 echo done >&2
+# training legs: bench line + kernel stats of the training step (set TRAIN="c3 c5 c2" to collect)
+for W in ${TRAIN:-}; do
+  echo "== $W train" >&2
+  timeout -k 10 400 python3 bench.py --workload $W --mode train --steps 5 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_bench_train_$W.jsonl 2> $OUT/${TAG}_bench_train_$W.err || exit 1
+  timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_train_$W -o run -- \
+    python3 bench.py --workload $W --mode train --steps 3 --warmup 1 --preheat-ms 0 --no-cpu-baseline > $OUT/${TAG}_prof_train_$W.log 2>&1 || exit 1
+  cp "$(find $OUT/${TAG}_prof_train_$W -name '*kernel_stats.csv' | head -1)" $OUT/${TAG}_bench_train_${W}_kernel_stats.csv
+  rm -rf $OUT/${TAG}_prof_train_$W
+done
+echo done-train >&2
