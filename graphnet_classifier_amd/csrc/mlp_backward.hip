@@ -1551,7 +1551,9 @@ extern "C" int gnc_mlp_backward_f32(const gnc_mlp_bwd_desc_t* bd, void* stream_)
     switch (T) {
       case 1: return launch_bwd_stream<1, 4>(d, b, pl, st);
       case 2: return launch_bwd_stream<2, 4>(d, b, pl, st);
-      default: return w4 ? launch_bwd_stream<4, 4>(d, b, pl, st) : launch_bwd_stream<4, 8>(d, b, pl, st);
+      default:
+        if (d.rows <= (int64_t)2 * RPW * gnc::num_cu()) return launch_bwd_stream<4, 2>(d, b, pl, st);  // small batch: see mlp_stream.hip
+        return w4 ? launch_bwd_stream<4, 4>(d, b, pl, st) : launch_bwd_stream<4, 8>(d, b, pl, st);
     }
   }
   const int total_chunks = nmm + (L - 1);
@@ -1628,6 +1630,52 @@ extern "C" int gnc_xty_f32(const float* A, int64_t lda, const float* B, int64_t 
 #undef GNC_XTY
   gnc::set_error("gnc_xty_f32: no instance for M = %d, K = %d", M, K);
   return GNC_ERR_UNSUPPORTED;
+}
+
+namespace {
+// out[j] = sum over p (a fixed order, reproducible) of partial[p * stride + j] for j < M * K + M; the first
+// M * K values go to dW (row-major, leading dimension ld_dw), the last M to db.  A workgroup = 64 columns x 8
+// partial-lanes: lane l of a column adds the partials p = l, l + 8, ... (loads of different lanes and of one lane's
+// unrolled group fly together: the small-graph regime is latency-bound), the eight lane sums are combined through LDS
+// in lane order.
+__global__ __launch_bounds__(512) void reduce_partials_kernel(const float* __restrict__ partial, int num_partials, int stride,
+                                                              int M, int K, float* __restrict__ dW, int64_t ld_dw,
+                                                              float* __restrict__ db) {
+  __shared__ float part[8][64];
+  const int col = (int)threadIdx.x & 63, pl = (int)threadIdx.x >> 6;
+  const int j = (int)blockIdx.x * 64 + col;
+  const int mk = M * K;
+  const int total = mk + (db ? M : 0);
+  float a4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (j < total) {
+    const float* p = partial + j;
+    int q = pl;
+    for (; q + 24 < num_partials; q += 32) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a4[u] += p[(int64_t)(q + 8 * u) * stride];
+    }
+    for (int u = 0; q < num_partials; q += 8, ++u) a4[u] += p[(int64_t)q * stride];
+  }
+  part[pl][col] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+  __syncthreads();
+  if (pl == 0 && j < total) {
+    float acc = 0.f;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) acc += part[l][col];
+    if (j < mk) dW[(int64_t)(j / K) * ld_dw + (j % K)] = acc;
+    else db[j - mk] = acc;
+  }
+}
+}  // namespace
+
+extern "C" int gnc_reduce_partials_f32(const float* partial, int32_t num_partials, int32_t stride, int32_t M, int32_t K,
+                                       float* dW, int64_t ld_dw, float* db, void* stream_) {
+  GNC_REQUIRE(partial && dW && num_partials >= 1 && M >= 1 && K >= 1 && stride >= M * K + (db ? M : 0) && ld_dw >= K,
+              "gnc_reduce_partials_f32: bad arguments");
+  const int total = M * K + (db ? M : 0);
+  reduce_partials_kernel<<<dim3((unsigned)((total + 63) / 64)), dim3(512), 0, (hipStream_t)stream_>>>(partial, num_partials, stride,
+                                                                                                     M, K, dW, ld_dw, db);
+  return gnc::check_launch("reduce_partials_kernel");
 }
 
 extern "C" int gnc_colsum_pair_f32(const float* G, int64_t ldg, const float* Y, int64_t ldy, int64_t rows, int32_t width,

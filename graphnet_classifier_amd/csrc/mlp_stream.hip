@@ -516,6 +516,12 @@ int gnc_mlp::launch_stream(const gnc_mlp_desc_t& d, int T, bool narrow_out, hipS
   }
   *launched = true;
   if (probe_only) return GNC_OK;
+  // Small batches (the reference's own regime: ONE ~1000-node graph per call, main.py:60): with 8-wave workgroups a
+  // 2,000-row launch is 8 workgroups, each streaming the whole weight sequence with nothing to overlap it (38 us per
+  // forward launch, 145 us per backward launch in the captured training step's trace).  2-wave workgroups spread the
+  // same rows over 4x as many CUs; the weights come out of L2 either way.
+  const bool small = T == 4 && d.rows <= (int64_t)2 * RPW * gnc::num_cu();
+  if (small) return narrow_out ? launch<4, 1, 2, true, true>(d, pl, stream) : launch<4, 4, 2, true, false>(d, pl, stream);
   if (narrow_out) {  // out width <= 32 (the decoder): one output tile
     switch (T) {
       case 1: return launch<1, 1, 8, true, true>(d, pl, stream);

@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 GNC_MAX_SEGMENTS = 4
 GNC_MAX_LINEAR = 8
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 ACTIVATIONS = {  # nn.<Name> accepted by the reference's MLP(activation=...) (models/MLP.py:21)
     "ReLU": 0, "Identity": 1, "Tanh": 2, "Sigmoid": 3, "SiLU": 4, "GELU": 5, "LeakyReLU": 6, "ELU": 7,
@@ -62,6 +62,7 @@ _SIGNATURES = {
     "gnc_rag_build": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
                                 c_void_p, c_size_t, c_void_p]),
     "gnc_colsum_pair_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_int32, c_void_p]),
+    "gnc_reduce_partials_f32": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_void_p]),
     "gnc_adam_step_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float,
                                     c_void_p, c_void_p, c_void_p]),
 }
@@ -573,10 +574,11 @@ def xty(a: torch.Tensor, b: torch.Tensor):
                 _check(_launch("xty", av, lambda: lib.gnc_xty_f32(av.data_ptr(), _ld(av), bv.data_ptr(), _ld(bv), rows, mm,
                                                                   kk, part.data_ptr(), p, _stream(av)),
                                2.0 * rows * mm * kk), "gnc_xty_f32")
-                tot = part.sum(dim=0)
-                c[m0:m0 + mm, k0:k0 + kk] = tot[:mm * kk].view(mm, kk)
-                if k0 == 0:
-                    colsum[m0:m0 + mm] = tot[mm * kk:]
+                # fixed-order sum of the per-wave partials straight into the block's place (one launch, no sum + copies)
+                cblk = c[m0:m0 + mm, k0:k0 + kk]
+                _check(lib.gnc_reduce_partials_f32(part.data_ptr(), p, mm * kk + mm, mm, kk, cblk.data_ptr(), c.stride(0),
+                                                   colsum[m0:m0 + mm].data_ptr() if k0 == 0 else None, _stream(av)),
+                       "gnc_reduce_partials_f32")
     return c, colsum
 
 
@@ -585,8 +587,7 @@ def colsum_pair(g: torch.Tensor, y: torch.Tensor):
     lib = load_library()
     g, y = _vector_rows(_rowmajor(g)), _vector_rows(_rowmajor(y))
     rows, width = g.shape
-    sg = torch.empty(width, dtype=torch.float32, device=g.device)
-    sgy = torch.empty(width, dtype=torch.float32, device=g.device)
+    both = torch.empty(2, width, dtype=torch.float32, device=g.device)  # row 0: colsum(G), row 1: colsum(G * Y)
     with torch.cuda.device(g.device):
         p = lib.gnc_xty_partials(rows)
         for c0 in range(0, width, 64):  # 64-column slabs (a wide LayerNorm is a few launches over column slices)
@@ -595,9 +596,9 @@ def colsum_pair(g: torch.Tensor, y: torch.Tensor):
             part = torch.empty(p, 2 * w, dtype=torch.float32, device=g.device)
             _check(lib.gnc_colsum_pair_f32(gs.data_ptr(), _ld(g), ys.data_ptr(), _ld(y), rows, w, part.data_ptr(), p,
                                            _stream(g)), "gnc_colsum_pair_f32")
-            tot = part.sum(dim=0)
-            sg[c0:c0 + w], sgy[c0:c0 + w] = tot[:w], tot[w:]
-    return sg, sgy
+            _check(lib.gnc_reduce_partials_f32(part.data_ptr(), p, 2 * w, 2, w, both[:, c0:c0 + w].data_ptr(), width, None,
+                                               _stream(g)), "gnc_reduce_partials_f32")
+    return both[0], both[1]
 
 
 # --------------------------------------------------------------------------- fused Adam

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GNC_ABI_VERSION 13
+#define GNC_ABI_VERSION 14
 
 enum {
   GNC_OK = 0,
@@ -270,6 +270,11 @@ int gnc_xty_f32(const float* A, int64_t lda, const float* B, int64_t ldb, int64_
                 float* partial, int32_t num_partials, void* stream);
 int gnc_colsum_pair_f32(const float* G, int64_t ldg, const float* Y, int64_t ldy, int64_t rows, int32_t width,
                         float* partial, int32_t num_partials, void* stream);
+/* Fixed-order sum of per-wave partial rows written by the kernels above (and by dw_partial / ln_partial):
+ * for j < M*K: dW[(j / K) * ld_dw + j % K] = sum_p partial[p * stride + j]; for j < M: db[j] = sum_p partial[p * stride + M*K + j]
+ * (db may be NULL).  Lets a weight-gradient block land in its place inside a larger matrix without a PyTorch sum + copies. */
+int gnc_reduce_partials_f32(const float* partial, int32_t num_partials, int32_t stride, int32_t M, int32_t K,
+                            float* dW, int64_t ld_dw, float* db, void* stream);
 
 /* ---- graph construction on the device ---------------------------
  * Inputs: an already resized uint8 RGB image [H, W, C] in HBM.  Outputs: the tensors
