@@ -154,7 +154,7 @@ def main():
     ap.add_argument("--objects", default=os.path.join(ROOT, "build", "csrc", "*.o"))
     ap.add_argument("-v", "--verbose", action="store_true")
     a = ap.parse_args()
-    objs = sorted(glob.glob(a.objects))
+    objs = sorted(o for o in glob.glob(a.objects) if not o.endswith("_probe.o"))  # developer probe builds are not shipped
     if not objs:
         print("check_isa: no objects under build/csrc (run make first)")
         return 1
