@@ -475,3 +475,26 @@ def test_deferred_validation_poisons_the_output_and_raises_at_the_check(G):
     finally:
         topology.set_validation("sync")
         topology.clear_topology_cache()
+
+
+@pytest.mark.parametrize("width", [40, 96, 160, 200])
+def test_hip_backward_odd_widths_agree_with_torch_recompute_backward(G, monkeypatch, width):
+    """Widths that are not a multiple of 64 (tails of the 64-column chunks, partial accumulator tiles) through every K8
+    width class, against the PyTorch-ROCm recompute backward of the same ops."""
+    from graphnet_classifier_amd import functional as Fn
+    from graphnet_classifier_amd import synthetic as S
+    batch = S.superpixel_like_graphs(4, seed=width)
+    x, pos, ei = batch.x.to(DEV), batch.pos.to(DEV), batch.edge_index.to(DEV)
+    w = torch.randn(batch.num_nodes, 1, device=DEV)
+    torch.manual_seed(width)
+    m = G.GraphNet(**S.graphnet_kwargs(width, 2))
+    grads = {}
+    for hip in (True, False):
+        monkeypatch.setattr(Fn, "HIP_BACKWARD", hip)
+        m.zero_grad()
+        (m(x, pos, ei) * w).sum().backward()
+        grads[hip] = {k: p.grad.clone() for k, p in m.named_parameters()}
+    for k in grads[True]:
+        a, b = grads[True][k], grads[False][k]
+        assert float((a - b).norm() / b.norm().clamp_min(1e-12)) < 1e-3, (width, k)
+        assert max_abs(a, b) < 3e-3 * max(1.0, float(b.abs().max())), (width, k)
