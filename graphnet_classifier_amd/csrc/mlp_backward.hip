@@ -845,6 +845,12 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_backward_stream_kernel(const g
   float* wbuf = lds;
   float* pbuf = lds + 2 * CH;
   float* abuf = pbuf + (L + 2) * PSTRIDE + wave * RPW * LDSW;
+  // LayerNorm parameter sums of the rows this wave processes (b.ln_partial): [colsum(grad_out) | colsum(grad_out * y_hat)],
+  // kept in LDS so that nothing is carried in registers across the tile loop
+  float* lnbuf = pbuf + (L + 2) * PSTRIDE + WAVES * RPW * LDSW + wave * 2 * PSTRIDE;
+  if (b.ln_partial) {
+    for (int j = lane; j < 2 * PSTRIDE; j += 64) lnbuf[j] = 0.f;
+  }
 
   stage_params<NT>(pbuf, d, PSTRIDE, tid);
 
@@ -1076,7 +1082,48 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_backward_stream_kernel(const g
     }
     if (d.ln_gamma) {
       layer_norm_backward_tiles<HT>(y, g, pbuf + L * PSTRIDE, out_dim, d.ln_eps, h);
-      emit(y, b.yhat, out_dim, out_dim, row0);
+      if (b.ln_partial) {
+        // d beta / d gamma in flight, one 64-column slab at a time: y_hat goes through the wave's LDS tile into whole-row
+        // pieces, grad_out's pieces come back through the window (the tile read them a moment ago: L2 hits; rows past
+        // the end read 0 and drop out); the four row groups are folded and the slab's 2 x 64 sums added to the wave's
+        // LDS totals.  Replaces the y_hat tensor ([rows, out] written here, read back by colsum_pair with grad_out).
+#pragma unroll
+        for (int cc = 0; cc < NCH; ++cc) {
+          if (cc * KC < out_dim) {
+            const int fl = fresh_lane();
+            const int c4 = fl & 15, rs = fl >> 4;
+            const int col = cc * KC + c4 * 4;
+            f32x4 gp[NP];
+            load_tile_rows(gp, b.grad_out, b.ld_grad_out, row0, rows, (uint32_t)(rs * b.ld_grad_out + (col < out_dim ? col : 0)) * 4u);
+            compiler_lds_barrier();
+            switch (cc) {
+              case 0: chunk_to_lds<HT, 0>(y, abuf, i, h); break;
+              case 1: chunk_to_lds<HT, 2>(y, abuf, i, h); break;
+              case 2: chunk_to_lds<HT, 4>(y, abuf, i, h); break;
+              default: chunk_to_lds<HT, 6>(y, abuf, i, h); break;
+            }
+            compiler_lds_barrier();
+            f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sgy = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+              const f32x4 yh = *reinterpret_cast<const f32x4*>(abuf + (p * 4 + rs) * LDSW + c4 * 4);
+              sg += gp[p];
+              sgy = __builtin_elementwise_fma(gp[p], yh, sgy);
+            }
+            sg.x = add_quarters(sg.x); sg.y = add_quarters(sg.y); sg.z = add_quarters(sg.z); sg.w = add_quarters(sg.w);
+            sgy.x = add_quarters(sgy.x); sgy.y = add_quarters(sgy.y); sgy.z = add_quarters(sgy.z); sgy.w = add_quarters(sgy.w);
+            if (rs == 0) {
+              f32x4* pg = reinterpret_cast<f32x4*>(lnbuf + col);
+              f32x4* py = reinterpret_cast<f32x4*>(lnbuf + PSTRIDE + col);
+              *pg = *pg + sg;
+              *py = *py + sgy;
+            }
+            compiler_lds_barrier();
+          }
+        }
+      } else {
+        emit(y, b.yhat, out_dim, out_dim, row0);
+      }
     } else {
 #pragma unroll
       for (int t = 0; t < HT; ++t)
@@ -1124,6 +1171,44 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_backward_stream_kernel(const g
       }
     }
   }
+  if (b.ln_partial) {  // one row of partials per wave: [d beta (out_dim) | d gamma (out_dim)]
+    compiler_lds_barrier();
+    float* dst = b.ln_partial + (int64_t)((int)blockIdx.x * WAVES + wave) * 2 * out_dim;
+    for (int j = fresh_lane(); j < PSTRIDE; j += 64)
+      if (j < out_dim) {
+        dst[j] = lnbuf[j];
+        dst[out_dim + j] = lnbuf[PSTRIDE + j];
+      }
+  }
+}
+
+// columns [c0, c0 + 64) of rows [32 tile, 32 tile + 32) of an operand ([rows, ld], `width` columns in all) as 8 pieces of
+// 16 B per lane (lane = (rs, c4): row 4 p + rs, columns 4 c4 ..), zero beyond `width` and past the last row
+__device__ __forceinline__ void xty_load_tile(f32x4 (&pre)[NP], const float* base, int64_t ld, int width, int c0, bool vec,
+                                              int tile, int rows, int c4, int rs) {
+  const int col = c0 + c4 * 4;
+  if (vec && c0 + KC <= width) {  // full slab: one buffer window per tile, rows past the end read as 0
+    load_tile_rows<true>(pre, base, (int)ld, (int64_t)tile * RPW, rows, (uint32_t)(rs * (int)ld + col) * 4u);
+    return;
+  }
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int r = tile * RPW + p * 4 + rs;
+    const int rc = r < rows ? r : rows - 1;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (vec) {
+      const int cc = col < width ? col : 0;
+      v = *reinterpret_cast<const f32x4*>(base + (int64_t)rc * ld + cc);
+    } else {  // narrow / unaligned operand (e.g. the 3-column inputs): scalar, still unconditional
+      const float* q = base + (int64_t)rc * ld;
+      v.x = q[col + 0 < width ? col + 0 : 0]; v.y = q[col + 1 < width ? col + 1 : 0];
+      v.z = q[col + 2 < width ? col + 2 : 0]; v.w = q[col + 3 < width ? col + 3 : 0];
+    }
+    const bool rok = r < rows;
+    v.x = (rok && col + 0 < width) ? v.x : 0.f; v.y = (rok && col + 1 < width) ? v.y : 0.f;
+    v.z = (rok && col + 2 < width) ? v.z : 0.f; v.w = (rok && col + 3 < width) ? v.w : 0.f;
+    pre[p] = v;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1165,31 +1250,8 @@ __global__ __launch_bounds__(256) void xty_kernel(const float* __restrict__ A, i
 #pragma unroll
   for (int a = 0; a < TM; ++a) csum[a] = 0.f;
 
-  // columns [c0, c0 + 64) of the operand, zero beyond `width` (the operand's total column count)
   auto load_tile = [&](f32x4 (&pre)[NP], const float* base, int64_t ld, int width, int c0, bool vec, int tile) {
-    const int col = c0 + c4 * 4;
-    if (vec && c0 + KC <= width) {  // full slab: one buffer window per tile, rows past the end read as 0
-      load_tile_rows<true>(pre, base, (int)ld, (int64_t)tile * RPW, rows, (uint32_t)(rs * (int)ld + col) * 4u);
-      return;
-    }
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      const int r = tile * RPW + p * 4 + rs;
-      const int rc = r < rows ? r : rows - 1;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (vec) {
-        const int cc = col < width ? col : 0;
-        v = *reinterpret_cast<const f32x4*>(base + (int64_t)rc * ld + cc);
-      } else {  // narrow / unaligned operand (e.g. the 3-column inputs): scalar, still unconditional
-        const float* q = base + (int64_t)rc * ld;
-        v.x = q[col + 0 < width ? col + 0 : 0]; v.y = q[col + 1 < width ? col + 1 : 0];
-        v.z = q[col + 2 < width ? col + 2 : 0]; v.w = q[col + 3 < width ? col + 3 : 0];
-      }
-      const bool rok = r < rows;
-      v.x = (rok && col + 0 < width) ? v.x : 0.f; v.y = (rok && col + 1 < width) ? v.y : 0.f;
-      v.z = (rok && col + 2 < width) ? v.z : 0.f; v.w = (rok && col + 3 < width) ? v.w : 0.f;
-      pre[p] = v;
-    }
+    xty_load_tile(pre, base, ld, width, c0, vec, tile, rows, c4, rs);
   };
 
   int tile = wave;
@@ -1248,6 +1310,125 @@ __global__ __launch_bounds__(256) void xty_kernel(const float* __restrict__ A, i
   for (int a = 0; a < TM; ++a) {
     const float tot = csum[a] + __shfl_xor(csum[a], 32, 64);
     if (h == 0 && 32 * a + i < M) dst[M * K + 32 * a + i] = tot;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// xty_wg: the same product for WIDE operands (both above 64 columns, up to 256 x 256) with the row tile SHARED by a
+// workgroup.  xty_kernel gives every wave its own rows and its own full [M, K] accumulator: at 128 x 128 that is 256
+// accumulator registers (one wave per SIMD: nothing covers the wave's own row loads, and the launch's MFMA time and
+// HBM time add up - 1.75 + 1.4 = 3.2 ms measured at c2), and a 256 x 256 gradient is four launches that read every
+// row slab twice.  Here the WVM x WVK waves of a workgroup own one (32 WM) x (32 WK) block of C each and multiply the
+// SAME 32-row tile: every wave brings in one 64-column slab of it (8 x 16 B per lane), parks it in the workgroup's
+// LDS tile set (double buffered: one barrier per tile) and reads its own operand columns down the rows.  Accumulators
+// per wave: 64 registers (128 x 128: 4 waves, two workgroups per CU) or 128 (256 x 256: 8 waves), so two waves share
+// a SIMD and each row of A and B is read from HBM once per launch.  One partial C per WORKGROUP.
+// ---------------------------------------------------------------------------------------------------
+template <int WM, int WK, int WVM, int WVK>
+__global__ __launch_bounds__(64 * WVM * WVK) void xty_wg_kernel(const float* __restrict__ A, int64_t lda,
+                                                                const float* __restrict__ B, int64_t ldb, int rows, int M,
+                                                                int K, float* __restrict__ partial, int pstride) {
+  static_assert((WM % 2 == 0 || WM == 1) && (WK % 2 == 0 || WK == 1), "a per-wave block may not straddle 64-column LDS tiles");
+  extern __shared__ __attribute__((aligned(16))) float xty_lds[];
+  constexpr int NW = WVM * WVK;
+  constexpr int NA = (WM * WVM + 1) / 2, NB = (WK * WVK + 1) / 2, NT = NA + NB;  // 64-column LDS tiles of A, of B
+  constexpr int LPW = (NT + NW - 1) / NW;                            // slabs a wave brings in per row tile
+  constexpr int TILE = RPW * LDSW;
+  const int lane = threadIdx.x & 63;
+  const int i = lane & 31;
+  const int h = lane >> 5;
+  const int c4 = lane & 15, rs = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int wm = w / WVK, wk = w % WVK;
+  const int num_tiles = (rows + RPW - 1) / RPW;
+  const bool avec = (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15u) == 0);
+  const bool bvec = (ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(B) & 15u) == 0);
+  f32x16 acc[WM][WK];
+#pragma unroll
+  for (int a = 0; a < WM; ++a)
+#pragma unroll
+    for (int c = 0; c < WK; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+  float csum[WM];
+#pragma unroll
+  for (int a = 0; a < WM; ++a) csum[a] = 0.f;
+
+  auto load_slab = [&](f32x4 (&pre)[NP], int t, int tile) {  // slab t < NA: A columns [64 t, ..), else B columns [64 (t - NA), ..)
+    const bool isa = t < NA;
+    xty_load_tile(pre, isa ? A : B, isa ? lda : ldb, isa ? M : K, (isa ? t : t - NA) * KC, isa ? avec : bvec, tile, rows, c4, rs);
+  };
+
+  int tile = (int)blockIdx.x;
+  f32x4 pre[LPW][NP];
+  if (tile < num_tiles) {
+#pragma unroll
+    for (int j = 0; j < LPW; ++j)
+      if (w + j * NW < NT) load_slab(pre[j], w + j * NW, tile);
+  }
+  // this wave's operand columns inside a tile set (loop constants; the two tile sets are NT * TILE floats apart)
+  const float* arow = xty_lds + ((wm * WM) >> 1) * TILE + 32 * ((wm * WM) & 1) + h * LDSW + i;
+  const float* brow = xty_lds + (NA + ((wk * WK) >> 1)) * TILE + 32 * ((wk * WK) & 1) + h * LDSW + i;
+  int cur = 0;
+  for (; tile < num_tiles; tile += (int)gridDim.x) {
+    float* set = xty_lds + cur * NT * TILE;
+#pragma unroll
+    for (int j = 0; j < LPW; ++j)
+      if (w + j * NW < NT) {
+        float* dstt = set + (w + j * NW) * TILE + rs * LDSW + c4 * 4;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) *reinterpret_cast<f32x4*>(dstt + p * 4 * LDSW) = pre[j][p];
+      }
+    __syncthreads();  // the tile set is complete; the other set was last read before the previous barrier
+    const int nt = tile + (int)gridDim.x;
+    const int ntc = nt < num_tiles ? nt : num_tiles - 1;  // clamped: always a legal read, ignored after the last tile
+#pragma unroll
+    for (int j = 0; j < LPW; ++j)
+      if (w + j * NW < NT) load_slab(pre[j], w + j * NW, ntc);
+    const float* ar = arow + cur * NT * TILE;
+    const float* br = brow + cur * NT * TILE;
+    // operand columns one step ahead of the MFMAs that use them (two register sets, fully unrolled: the LDS round trip
+    // of step s + 1 runs under the MFMAs of step s)
+    float av[2][WM], bv[2][WK];
+    auto read_step = [&](int s, int set) {
+#pragma unroll
+      for (int a = 0; a < WM; ++a) av[set][a] = ar[(a >> 1) * TILE + 2 * s * LDSW + 32 * (a & 1)];
+#pragma unroll
+      for (int c = 0; c < WK; ++c) bv[set][c] = br[(c >> 1) * TILE + 2 * s * LDSW + 32 * (c & 1)];
+    };
+    read_step(0, 0);
+#pragma unroll
+    for (int s = 0; s < RPW / 2; ++s) {
+      if (s + 1 < RPW / 2) read_step(s + 1, (s + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);  // keep the reads in front of this step's MFMAs (the scheduler sinks them to their use)
+#pragma unroll
+      for (int a = 0; a < WM; ++a) csum[a] += av[s & 1][a];
+#pragma unroll
+      for (int a = 0; a < WM; ++a)
+#pragma unroll
+        for (int c = 0; c < WK; ++c) acc[a][c] = mfma(av[s & 1][a], bv[s & 1][c], acc[a][c]);
+    }
+    cur ^= 1;
+  }
+  // partial layout per workgroup: [M*K] row-major C, then [M] column sums (written by the waves of the first block column)
+  float* dst = partial + (int64_t)blockIdx.x * pstride;
+#pragma unroll
+  for (int a = 0; a < WM; ++a)
+#pragma unroll
+    for (int c = 0; c < WK; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = 32 * (wm * WM + a) + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int k = 32 * (wk * WK + c) + i;
+        if (m < M && k < K) dst[m * K + k] = acc[a][c][r];
+      }
+  if (wk == 0) {
+#pragma unroll
+    for (int a = 0; a < WM; ++a) {
+      const float tot = csum[a] + __shfl_xor(csum[a], 32, 64);
+      const int m = 32 * (wm * WM + a) + i;
+      if (h == 0 && m < M) dst[M * K + m] = tot;
+    }
   }
 }
 
@@ -1396,7 +1577,8 @@ bool bwd_stream_plan(const gnc_mlp_desc_t& d, bool want_dx, BwdPlan* pl, int* T_
 
 template <int HT, int WAVES>
 int launch_bwd_stream(const gnc_mlp_desc_t& d, const BwdArgs& b, const BwdPlan& pl, hipStream_t stream) {
-  const size_t smem = ((size_t)2 * HT * 32 * LDSW + (size_t)(d.num_linear + 2) * HT * 32 + (size_t)WAVES * RPW * LDSW) * sizeof(float);
+  const size_t smem = ((size_t)2 * HT * 32 * LDSW + (size_t)(d.num_linear + 2) * HT * 32 + (size_t)WAVES * RPW * LDSW +
+                       (size_t)WAVES * 2 * HT * 32) * sizeof(float);
   if (smem > 160 * 1024) { gnc::set_error("mlp_backward_stream: LDS budget exceeded"); return GNC_ERR_UNSUPPORTED; }
   static bool attr_set = false;
   if (!attr_set) {
@@ -1410,6 +1592,14 @@ int launch_bwd_stream(const gnc_mlp_desc_t& d, const BwdArgs& b, const BwdPlan& 
   const int64_t grid = num_tiles < gnc::num_cu() ? num_tiles : gnc::num_cu();
   mlp_backward_stream_kernel<HT, WAVES><<<dim3((unsigned)grid), dim3(WAVES * 64), smem, stream>>>(d, b, pl, (int)num_tiles);
   return gnc::check_launch("mlp_backward_stream_kernel");
+}
+
+// waves per workgroup of the 32-row streaming kernel for T 32-column tiles (the dispatch below and the partial-row query)
+int bwd_stream_waves(int T, int64_t rows) {
+  static const bool w4 = getenv("GNC_BWD_STREAM_W4") != nullptr;  // A/B: the 4-wave (one per SIMD, 512 registers) form at 128
+  if (T < 4) return 4;
+  if (rows <= (int64_t)2 * RPW * gnc::num_cu()) return 2;  // small batch: see mlp_stream.hip
+  return w4 ? 4 : 8;
 }
 
 int bwd_grid(int64_t rows) {
@@ -1530,8 +1720,8 @@ extern "C" int gnc_mlp_backward_f32(const gnc_mlp_bwd_desc_t* bd, void* stream_)
     GNC_REQUIRE(l == L - 1 || bd->act[l], "gnc_mlp_backward_f32: act[%d] is null", l);
   }
   const int grid = bwd_grid(d.rows);
-  GNC_REQUIRE(!d.ln_gamma || bd->yhat || (resident && bd->ln_partial),
-              "gnc_mlp_backward_f32: with LayerNorm either yhat or (weights-resident shapes) ln_partial is required");
+  GNC_REQUIRE(!d.ln_gamma || bd->yhat || ((resident || stream32) && bd->ln_partial),
+              "gnc_mlp_backward_f32: with LayerNorm either yhat or (32-row kernels) ln_partial is required");
   GNC_REQUIRE(!bd->dx || bd->ld_dx >= d.in_dim[0], "gnc_mlp_backward_f32: ld_dx < in_dim[0]");
 
   BwdArgs b = {};
@@ -1542,18 +1732,19 @@ extern "C" int gnc_mlp_backward_f32(const gnc_mlp_bwd_desc_t* bd, void* stream_)
   b.ld_dx = bd->ld_dx;
   b.yhat = d.ln_gamma ? bd->yhat : nullptr;
   b.dx_add_grad_out = (resident && bd->dx_add_grad_out) ? 1 : 0;
-  b.ln_partial = (resident && d.ln_gamma) ? bd->ln_partial : nullptr;
+  b.ln_partial = ((resident || stream32) && d.ln_gamma) ? bd->ln_partial : nullptr;
 
   if (stream16) return launch_bwd_stream16(d, b, (hipStream_t)stream_);
   if (!resident) {
     hipStream_t st = (hipStream_t)stream_;
-    static const bool w4 = getenv("GNC_BWD_STREAM_W4") != nullptr;  // A/B: the 4-wave (one per SIMD, 512 registers) form at 128
     switch (T) {
       case 1: return launch_bwd_stream<1, 4>(d, b, pl, st);
       case 2: return launch_bwd_stream<2, 4>(d, b, pl, st);
-      default:
-        if (d.rows <= (int64_t)2 * RPW * gnc::num_cu()) return launch_bwd_stream<4, 2>(d, b, pl, st);  // small batch: see mlp_stream.hip
-        return w4 ? launch_bwd_stream<4, 4>(d, b, pl, st) : launch_bwd_stream<4, 8>(d, b, pl, st);
+      default: {
+        const int wv = bwd_stream_waves(T, d.rows);
+        if (wv == 2) return launch_bwd_stream<4, 2>(d, b, pl, st);
+        return wv == 4 ? launch_bwd_stream<4, 4>(d, b, pl, st) : launch_bwd_stream<4, 8>(d, b, pl, st);
+      }
     }
   }
   const int total_chunks = nmm + (L - 1);
@@ -1584,9 +1775,16 @@ extern "C" int gnc_mlp_backward_fused_rows(const gnc_mlp_desc_t* fwd) {
 
 extern "C" int gnc_mlp_backward_ln_partial_rows(const gnc_mlp_desc_t* fwd) {
   if (!fwd || gnc_mlp::validate_desc(fwd, false) != GNC_OK || !fwd->ln_gamma) return 0;
+  static const bool off = getenv("GNC_NO_STREAM_LN_SUMS") != nullptr;  // A/B switch
   int nmm = 0, nadd = 0, T = 0;
-  if (!bwd_shape(*fwd, &nmm, &nadd, &T)) return 0;  // in-flight sums: the weights-resident data kernel only
-  return bwd_grid(fwd->rows) * BWAVES;
+  if (bwd_shape(*fwd, &nmm, &nadd, &T)) return bwd_grid(fwd->rows) * BWAVES;
+  BwdPlan pl;
+  if (!off && bwd_stream_plan(*fwd, true, &pl, &T)) {  // the 32-row streaming kernel: one row per wave of its grid
+    const int wv = bwd_stream_waves(T, fwd->rows);
+    const int64_t tiles = gnc::ceil_div(fwd->rows, (int64_t)wv * RPW);
+    return (int)(tiles < gnc::num_cu() ? tiles : gnc::num_cu()) * wv;
+  }
+  return 0;  // the 16-row kernel writes y_hat (gnc_colsum_pair_f32 forms the sums)
 }
 
 extern "C" int gnc_xty_partials(int64_t rows) {
@@ -1617,16 +1815,61 @@ int launch_xty(const float* A, int64_t lda, const float* B, int64_t ldb, int row
 inline int blocks32(int w) { return w <= 32 ? 1 : w <= 64 ? 2 : 4; }
 }  // namespace
 
+namespace {
+// workgroup-shared instances (xty_wg_kernel): which one serves [M, K], 0 = the per-wave kernel
+inline int xty_wg_shape(int M, int K) {
+  if (M > 256 || K > 256 || M <= 64 || K <= 64) return 0;  // a narrow operand: the per-wave kernel (<= 128 columns each)
+  if (M <= 128 && K <= 128) return 1;  // 128 x 128: 4 waves x (64 x 64)
+  if (M <= 128) return 2;              // 128 x 256: 8 waves x (64 x 64)
+  if (K <= 128) return 3;              // 256 x 128: 8 waves x (64 x 64)
+  return 4;                            // 256 x 256: 8 waves x (128 x 64)
+}
+inline int xty_wg_groups(int shape, int64_t rows) {
+  const int64_t tiles = gnc::ceil_div(rows > 0 ? rows : 1, RPW);
+  const int64_t cap = (int64_t)gnc::num_cu() * (shape == 1 ? 2 : 1);
+  return (int)(tiles < cap ? tiles : cap);
+}
+template <int WM, int WK, int WVM, int WVK>
+int launch_xty_wg(const float* A, int64_t lda, const float* B, int64_t ldb, int rows, int M, int K, float* partial, int groups,
+                  hipStream_t stream) {
+  constexpr int NT = (WM * WVM + 1) / 2 + (WK * WVK + 1) / 2;
+  constexpr size_t smem = (size_t)2 * NT * RPW * LDSW * sizeof(float);
+  static_assert(smem <= 160 * 1024, "xty_wg: LDS budget");
+  static bool attr_set = false;
+  if (!attr_set) {
+    int rc = gnc::check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&xty_wg_kernel<WM, WK, WVM, WVK>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                            "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    if (rc) return rc;
+    attr_set = true;
+  }
+  xty_wg_kernel<WM, WK, WVM, WVK><<<dim3((unsigned)groups), dim3(64 * WVM * WVK), smem, stream>>>(A, lda, B, ldb, rows, M, K,
+                                                                                                    partial, M * K + M);
+  return gnc::check_launch("xty_wg_kernel");
+}
+}  // namespace
+
+extern "C" int gnc_xty_partials_for(int64_t rows, int32_t M, int32_t K) {
+  const int shape = xty_wg_shape(M, K);
+  return shape ? xty_wg_groups(shape, rows) : gnc_xty_partials(rows);
+}
+
 extern "C" int gnc_xty_f32(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t rows, int32_t M, int32_t K,
                            float* partial, int32_t num_partials, void* stream_) {
-  GNC_REQUIRE(rows >= 1 && rows < INT32_MAX && M >= 1 && K >= 1 && M <= 128 && K <= 128, "gnc_xty_f32: need 1 <= M, K <= 128");
+  GNC_REQUIRE(rows >= 1 && rows < INT32_MAX && M >= 1 && K >= 1 && M <= 256 && K <= 256, "gnc_xty_f32: need 1 <= M, K <= 256");
   GNC_REQUIRE(A && B && partial && lda >= M && ldb >= K, "gnc_xty_f32: null pointer or leading dimension too small");
-  const int waves = gnc_xty_partials(rows);
-  GNC_REQUIRE(num_partials >= waves, "gnc_xty_f32: partial buffer smaller than gnc_xty_partials()");
+  const int shape = xty_wg_shape(M, K);
+  GNC_REQUIRE(shape || (M <= 128 && K <= 128), "gnc_xty_f32: a narrow operand (<= 64 columns) next to one above 128: split the wide one");
+  const int parts = gnc_xty_partials_for(rows, M, K);
+  GNC_REQUIRE(num_partials >= parts, "gnc_xty_f32: partial buffer smaller than gnc_xty_partials_for()");
   hipStream_t stream = (hipStream_t)stream_;
+  if (shape == 1) return launch_xty_wg<2, 2, 2, 2>(A, lda, B, ldb, (int)rows, M, K, partial, parts, stream);
+  if (shape == 2) return launch_xty_wg<2, 2, 2, 4>(A, lda, B, ldb, (int)rows, M, K, partial, parts, stream);
+  if (shape == 3) return launch_xty_wg<2, 2, 4, 2>(A, lda, B, ldb, (int)rows, M, K, partial, parts, stream);
+  if (shape == 4) return launch_xty_wg<4, 2, 2, 4>(A, lda, B, ldb, (int)rows, M, K, partial, parts, stream);
   const int tm = blocks32(M), tk = blocks32(K);
-#define GNC_XTY(TM_, TK_) if (tm == TM_ && tk == TK_) return launch_xty<TM_, TK_>(A, lda, B, ldb, (int)rows, M, K, partial, waves, stream)
-  GNC_XTY(1, 1); GNC_XTY(1, 2); GNC_XTY(1, 4); GNC_XTY(2, 1); GNC_XTY(2, 2); GNC_XTY(2, 4); GNC_XTY(4, 1); GNC_XTY(4, 2); GNC_XTY(4, 4);
+#define GNC_XTY(TM_, TK_) if (tm == TM_ && tk == TK_) return launch_xty<TM_, TK_>(A, lda, B, ldb, (int)rows, M, K, partial, parts, stream)
+  GNC_XTY(1, 1); GNC_XTY(1, 2); GNC_XTY(1, 4); GNC_XTY(2, 1); GNC_XTY(2, 2); GNC_XTY(2, 4); GNC_XTY(4, 1); GNC_XTY(4, 2);
 #undef GNC_XTY
   gnc::set_error("gnc_xty_f32: no instance for M = %d, K = %d", M, K);
   return GNC_ERR_UNSUPPORTED;

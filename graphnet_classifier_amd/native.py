@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 GNC_MAX_SEGMENTS = 4
 GNC_MAX_LINEAR = 8
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 ACTIVATIONS = {  # nn.<Name> accepted by the reference's MLP(activation=...) (models/MLP.py:21)
     "ReLU": 0, "Identity": 1, "Tanh": 2, "Sigmoid": 3, "SiLU": 4, "GELU": 5, "LeakyReLU": 6, "ELU": 7,
@@ -53,6 +53,7 @@ _SIGNATURES = {
     "gnc_mlp_backward_fused_rows": (c_int32, [c_void_p]),
     "gnc_mlp_backward_f32": (c_int32, [c_void_p, c_void_p]),
     "gnc_xty_partials": (c_int32, [c_int64]),
+    "gnc_xty_partials_for": (c_int32, [c_int64, c_int32, c_int32]),
     "gnc_xty_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, c_void_p, c_int32, c_void_p]),
     "gnc_grid_num_edges": (c_int64, [c_int32, c_int32, c_int32]),
     "gnc_grid_edges_i64": (c_int32, [c_int32, c_int32, c_int32, c_void_p, c_void_p]),
@@ -553,9 +554,14 @@ def mlp_backward(segments, weights, biases, ln, grad_out: torch.Tensor, rows: in
             "_keep": (segs, w, b, g)}
 
 
+def _xty_spans(n: int, step: int):
+    return [(i, min(step, n - i)) for i in range(0, n, step)]
+
+
 def xty(a: torch.Tensor, b: torch.Tensor):
     """(A^T B [M, K], column sums of A [M]) over the rows; A [rows, M], B [rows, K] fp32.  Blocks of up to
-    128 x 128 per launch; per-wave partials are summed in a fixed order (bitwise reproducible)."""
+    256 x 256 per launch when both operands are wider than 64 columns (workgroup-shared row tiles), 128 x 128 next to
+    a narrow operand; the per-worker partials are summed in a fixed order (bitwise reproducible)."""
     lib = load_library()
     _require_cuda(a, b)
     a, b = _rowmajor(a), _rowmajor(b)
@@ -563,22 +569,26 @@ def xty(a: torch.Tensor, b: torch.Tensor):
     dev = a.device
     c = torch.empty(m, k, dtype=torch.float32, device=dev)
     colsum = torch.empty(m, dtype=torch.float32, device=dev)
+    blocks = []
+    for m0, mm in _xty_spans(m, 256 if k > 64 else 128):
+        for k0, kk in _xty_spans(k, 256 if mm > 64 else 128):
+            if kk <= 64 and mm > 128:  # a narrow remainder of k next to a wide block of m: the per-wave kernel's limit
+                blocks += [(m1 + m0, mm1, k0, kk) for m1, mm1 in _xty_spans(mm, 128)]
+            else:
+                blocks.append((m0, mm, k0, kk))
     with torch.cuda.device(dev):
-        p = lib.gnc_xty_partials(rows)
-        for m0 in range(0, m, 128):
-            mm = min(128, m - m0)
-            for k0 in range(0, k, 128):
-                kk = min(128, k - k0)
-                part = torch.empty(p, mm * kk + mm, dtype=torch.float32, device=dev)
-                av, bv = a[:, m0:m0 + mm], b[:, k0:k0 + kk]
-                _check(_launch("xty", av, lambda: lib.gnc_xty_f32(av.data_ptr(), _ld(av), bv.data_ptr(), _ld(bv), rows, mm,
-                                                                  kk, part.data_ptr(), p, _stream(av)),
-                               2.0 * rows * mm * kk), "gnc_xty_f32")
-                # fixed-order sum of the per-wave partials straight into the block's place (one launch, no sum + copies)
-                cblk = c[m0:m0 + mm, k0:k0 + kk]
-                _check(lib.gnc_reduce_partials_f32(part.data_ptr(), p, mm * kk + mm, mm, kk, cblk.data_ptr(), c.stride(0),
-                                                   colsum[m0:m0 + mm].data_ptr() if k0 == 0 else None, _stream(av)),
-                       "gnc_reduce_partials_f32")
+        for m0, mm, k0, kk in blocks:
+            p = lib.gnc_xty_partials_for(rows, mm, kk)
+            part = torch.empty(p, mm * kk + mm, dtype=torch.float32, device=dev)
+            av, bv = a[:, m0:m0 + mm], b[:, k0:k0 + kk]
+            _check(_launch("xty", av, lambda: lib.gnc_xty_f32(av.data_ptr(), _ld(av), bv.data_ptr(), _ld(bv), rows, mm,
+                                                              kk, part.data_ptr(), p, _stream(av)),
+                           2.0 * rows * mm * kk), "gnc_xty_f32")
+            # fixed-order sum of the partials straight into the block's place (one launch, no sum + copies)
+            cblk = c[m0:m0 + mm, k0:k0 + kk]
+            _check(lib.gnc_reduce_partials_f32(part.data_ptr(), p, mm * kk + mm, mm, kk, cblk.data_ptr(), c.stride(0),
+                                               colsum[m0:m0 + mm].data_ptr() if k0 == 0 else None, _stream(av)),
+                   "gnc_reduce_partials_f32")
     return c, colsum
 
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GNC_ABI_VERSION 14
+#define GNC_ABI_VERSION 15
 
 enum {
   GNC_OK = 0,
@@ -227,9 +227,11 @@ int gnc_agg_fixup_f32(const float* src, int64_t ld_src, const int32_t* rowptr, c
  *   (v_mfma_f32_16x16x4_f32; both streaming forms need 16-B aligned weights, the 16-row one stated gather tables);
  *   gnc_mlp_backward_supported() answers from the shape fields alone.
  *
- * gnc_xty_f32: partial[w] = [ A^T B (M x K, row-major) | column sums of A (M) ] over the rows wave w
- *   streamed; sum the num_partials = gnc_xty_partials(rows) rows (fixed order => reproducible).  M, K <= 128
- *   (a 256 x 256 weight gradient is four launches over [rows, 128] column slabs).
+ * gnc_xty_f32: partial[w] = [ A^T B (M x K, row-major) | column sums of A (M) ] over the rows worker w
+ *   streamed; sum the gnc_xty_partials_for(rows, M, K) rows it writes (fixed order => reproducible).  Both operands
+ *   above 64 columns: M, K <= 256, one partial per WORKGROUP (the row tile is shared by the workgroup's waves, each
+ *   row of A and B is read once per launch); otherwise M, K <= 128 and one partial per wave
+ *   (= gnc_xty_partials(rows), which is also an upper bound of every count).
  * gnc_colsum_pair_f32: partial[w] = [ colsum(G) (width) | colsum(G * Y) (width) ], same partial count.
  */
 typedef struct gnc_mlp_bwd_desc {
@@ -266,6 +268,7 @@ int gnc_mlp_backward_ln_partial_rows(const gnc_mlp_desc_t* fwd /* host */);
 int gnc_mlp_backward_fused_rows(const gnc_mlp_desc_t* fwd /* host */);
 int gnc_mlp_backward_f32(const gnc_mlp_bwd_desc_t* desc /* host */, void* stream);
 int gnc_xty_partials(int64_t rows);
+int gnc_xty_partials_for(int64_t rows, int32_t M, int32_t K);
 int gnc_xty_f32(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t rows, int32_t M, int32_t K,
                 float* partial, int32_t num_partials, void* stream);
 int gnc_colsum_pair_f32(const float* G, int64_t ldg, const float* Y, int64_t ldy, int64_t rows, int32_t width,

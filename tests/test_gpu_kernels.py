@@ -404,10 +404,14 @@ def test_mlp_rejects_unsupported(native):
 
 # ------------------------------------------------------------------ K8 backward kernels
 @pytest.mark.parametrize("m,k", [(64, 64), (64, 3), (16, 40), (128, 64), (64, 192), (128, 128), (256, 256), (130, 70), (96, 256),
-                                 (256, 4)])
-def test_xty_matches_matmul(native, m, k):
+                                 (256, 4), (65, 65), (200, 296), (100, 296), (256, 512), (1, 256), (128, 256), (256, 128),
+                                 (129, 129), (300, 90)])
+@pytest.mark.parametrize("rows", [4099, 31])
+def test_xty_matches_matmul(native, m, k, rows):
+    """Every block shape of the weight-gradient product: the per-wave kernel (a narrow operand), the four workgroup-shared
+    instances (128 x 128, 128 x 256, 256 x 128, 256 x 256), operands split into several blocks, ragged column counts,
+    fewer rows than one tile."""
     rng = np.random.default_rng(m * 7 + k)
-    rows = 4099
     a = torch.from_numpy(rng.standard_normal((rows, m)).astype(np.float32))
     b = torch.from_numpy(rng.standard_normal((rows, k)).astype(np.float32))
     c, cs = native.xty(a.to(DEV), b.to(DEV))
@@ -417,6 +421,13 @@ def test_xty_matches_matmul(native, m, k):
     assert max_abs(cs.cpu(), a.double().sum(0).float()) < 1e-3
     c2, _ = native.xty(a.to(DEV), b.to(DEV))
     assert torch.equal(c, c2)  # fixed summation order
+    # operands that are column slices of wider tensors (leading dimension > width, as the backward hands them over)
+    wide_a = torch.randn(rows, m + 8, device=DEV)
+    wide_b = torch.randn(rows, k + 12, device=DEV)
+    wide_a[:, 4:4 + m] = a.to(DEV)
+    wide_b[:, 8:8 + k] = b.to(DEV)
+    c3, cs3 = native.xty(wide_a[:, 4:4 + m], wide_b[:, 8:8 + k])
+    assert torch.equal(c3, c) and torch.equal(cs3, cs)
 
 
 @pytest.mark.parametrize("width", [64, 40, 128, 200, 256])

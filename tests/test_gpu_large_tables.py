@@ -174,3 +174,28 @@ def test_mlp_backward_row_tables_beyond_4gib(native, width):
         assert torch.equal(a[lo:], b)
     for a, b in zip(r["act"], r2["act"]):
         assert torch.equal(a[lo:], b)
+
+
+@pytest.mark.parametrize("width", [128, 256])
+def test_weight_gradient_product_beyond_4gib(native, width):
+    """xty (dW = dz^T a, db = colsum(dz)) with both operands larger than 4 GiB: against a float64 product, and the rows
+    beyond the offset alone (handed over as their own table) against the difference of the two."""
+    rows = _rows_for(width, 12_345)
+    gen = torch.Generator(device=DEV).manual_seed(width + 3)
+    a = torch.randn(rows, width, device=DEV, generator=gen)
+    b = torch.randn(rows, width, device=DEV, generator=gen)
+    c, cs = native.xty(a, b)
+    edge = FOUR_GIB // (4 * width)
+    ref = torch.zeros(width, width, dtype=torch.float64, device=DEV)
+    ref_hi = torch.zeros_like(ref)
+    for r0 in range(0, rows, 1 << 20):  # float64 in slabs: no second copy of the tables
+        blk = a[r0:r0 + (1 << 20)].double().t() @ b[r0:r0 + (1 << 20)].double()
+        ref += blk
+        if r0 >= edge:
+            ref_hi += blk
+    scale = float(ref.abs().max())
+    assert float((c.double() - ref).abs().max()) / scale < 1e-4
+    assert float((cs.double() - a.double().sum(0)).abs().max()) < 0.5  # sums of ~4 M N(0,1) values
+    first_hi = ((edge + (1 << 20) - 1) >> 20) << 20
+    c_hi, _ = native.xty(a[first_hi:], b[first_hi:])
+    assert float((c_hi.double() - ref_hi).abs().max()) / max(1.0, float(ref_hi.abs().max())) < 1e-4
