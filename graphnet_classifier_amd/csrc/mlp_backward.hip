@@ -1720,8 +1720,7 @@ extern "C" int gnc_mlp_backward_f32(const gnc_mlp_bwd_desc_t* bd, void* stream_)
     GNC_REQUIRE(l == L - 1 || bd->act[l], "gnc_mlp_backward_f32: act[%d] is null", l);
   }
   const int grid = bwd_grid(d.rows);
-  GNC_REQUIRE(!d.ln_gamma || bd->yhat || ((resident || stream32) && bd->ln_partial),
-              "gnc_mlp_backward_f32: with LayerNorm either yhat or (32-row kernels) ln_partial is required");
+  GNC_REQUIRE(!d.ln_gamma || bd->yhat || bd->ln_partial, "gnc_mlp_backward_f32: with LayerNorm either yhat or ln_partial is required");
   GNC_REQUIRE(!bd->dx || bd->ld_dx >= d.in_dim[0], "gnc_mlp_backward_f32: ld_dx < in_dim[0]");
 
   BwdArgs b = {};
@@ -1732,7 +1731,7 @@ extern "C" int gnc_mlp_backward_f32(const gnc_mlp_bwd_desc_t* bd, void* stream_)
   b.ld_dx = bd->ld_dx;
   b.yhat = d.ln_gamma ? bd->yhat : nullptr;
   b.dx_add_grad_out = (resident && bd->dx_add_grad_out) ? 1 : 0;
-  b.ln_partial = ((resident || stream32) && d.ln_gamma) ? bd->ln_partial : nullptr;
+  b.ln_partial = d.ln_gamma ? bd->ln_partial : nullptr;
 
   if (stream16) return launch_bwd_stream16(d, b, (hipStream_t)stream_);
   if (!resident) {
@@ -1775,16 +1774,22 @@ extern "C" int gnc_mlp_backward_fused_rows(const gnc_mlp_desc_t* fwd) {
 
 extern "C" int gnc_mlp_backward_ln_partial_rows(const gnc_mlp_desc_t* fwd) {
   if (!fwd || gnc_mlp::validate_desc(fwd, false) != GNC_OK || !fwd->ln_gamma) return 0;
-  static const bool off = getenv("GNC_NO_STREAM_LN_SUMS") != nullptr;  // A/B switch
+  static const bool off = getenv("GNC_NO_STREAM_LN_SUMS") != nullptr;  // A/B switch: the streaming kernels write y_hat again
   int nmm = 0, nadd = 0, T = 0;
   if (bwd_shape(*fwd, &nmm, &nadd, &T)) return bwd_grid(fwd->rows) * BWAVES;
+  if (off) return 0;
+  // the streaming kernels: the answer must not depend on whether the caller will ask for dx (the chunk plans do)
   BwdPlan pl;
-  if (!off && bwd_stream_plan(*fwd, true, &pl, &T)) {  // the 32-row streaming kernel: one row per wave of its grid
+  int T0 = 0;
+  const bool s32 = bwd_stream_plan(*fwd, true, &pl, &T), s32_nodx = bwd_stream_plan(*fwd, false, &pl, &T0);
+  if (s32 != s32_nodx || (s32 && T != T0)) return 0;
+  if (s32) {  // the 32-row kernel: one row per wave of its grid
     const int wv = bwd_stream_waves(T, fwd->rows);
     const int64_t tiles = gnc::ceil_div(fwd->rows, (int64_t)wv * RPW);
     return (int)(tiles < gnc::num_cu() ? tiles : gnc::num_cu()) * wv;
   }
-  return 0;  // the 16-row kernel writes y_hat (gnc_colsum_pair_f32 forms the sums)
+  if (use_stream16(*fwd, true) && use_stream16(*fwd, false)) return bwd_stream16_ln_partial_rows(fwd->rows);
+  return 0;
 }
 
 extern "C" int gnc_xty_partials(int64_t rows) {

@@ -176,6 +176,11 @@ __global__ __launch_bounds__(NT16) void mlp_backward_stream16_kernel(const gnc_m
   float* wbuf = lds;
   float* pbuf = lds + CH;
   float* abuf = pbuf + (L + 2) * PSTRIDE + wave * R16 * LDSW;
+  // LayerNorm parameter sums of this wave's rows (b.ln_partial): [colsum(grad_out) | colsum(grad_out * y_hat)], in LDS
+  float* lnbuf = pbuf + (L + 2) * PSTRIDE + W16 * R16 * LDSW + wave * 2 * PSTRIDE;
+  if (b.ln_partial) {
+    for (int j = lane; j < 2 * PSTRIDE; j += 64) lnbuf[j] = 0.f;
+  }
 
   stage_params<NT16>(pbuf, d, PSTRIDE, tid);
 
@@ -392,7 +397,43 @@ __global__ __launch_bounds__(NT16) void mlp_backward_stream16_kernel(const gnc_m
       init_bias16<NTL>(y, pbuf + (L - 1) * PSTRIDE, g);
       GNC_B16_FWD(0, y, L - 1) GNC_B16_FWD(1, y, L - 1) GNC_B16_FWD(2, y, L - 1) GNC_B16_FWD(3, y, L - 1)
       layer_norm_backward16<NTL>(y, gr, pbuf + L * PSTRIDE, out_dim, d.ln_eps, g);
-      emit(y, b.yhat, out_dim, out_dim, row0);  // normalised pre-affine output: d gamma = colsum(grad_out * y_hat)
+      if (b.ln_partial) {
+        // d beta / d gamma in flight (as in mlp_backward_stream_kernel): per 64-column slab y_hat goes through the wave's
+        // LDS tile into whole-row pieces, grad_out's pieces come back through the window (L2 hits; rows past the end read
+        // 0), the four row groups are folded and added to the wave's LDS totals.  No y_hat tensor, no colsum pass.
+#pragma unroll
+        for (int cc = 0; cc < NCH; ++cc) {
+          if (cc * KC < out_dim) {
+            const int col = cc * KC + c4 * 4;
+            f32x4 gp[NP16];
+            load_tile_rows<false, NP16>(gp, b.grad_out, b.ld_grad_out, row0, rows,
+                                        (uint32_t)(rs * b.ld_grad_out + (col < out_dim ? col : 0)) * 4u);
+            compiler_lds_barrier();
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+              if (4 * cc + cb < NTL) *reinterpret_cast<f32x4*>(abuf + i * LDSW + 16 * cb + 4 * g) = y[4 * cc + cb < NTL ? 4 * cc + cb : 0];
+            compiler_lds_barrier();
+            f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sgy = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int p = 0; p < NP16; ++p) {
+              const f32x4 yh = *reinterpret_cast<const f32x4*>(abuf + (p * 4 + rs) * LDSW + c4 * 4);
+              sg += gp[p];
+              sgy = __builtin_elementwise_fma(gp[p], yh, sgy);
+            }
+            sg.x = add_quarters(sg.x); sg.y = add_quarters(sg.y); sg.z = add_quarters(sg.z); sg.w = add_quarters(sg.w);
+            sgy.x = add_quarters(sgy.x); sgy.y = add_quarters(sgy.y); sgy.z = add_quarters(sgy.z); sgy.w = add_quarters(sgy.w);
+            if (rs == 0) {
+              f32x4* pg = reinterpret_cast<f32x4*>(lnbuf + col);
+              f32x4* py = reinterpret_cast<f32x4*>(lnbuf + PSTRIDE + col);
+              *pg = *pg + sg;
+              *py = *py + sgy;
+            }
+            compiler_lds_barrier();
+          }
+        }
+      } else {
+        emit(y, b.yhat, out_dim, out_dim, row0);  // normalised pre-affine output: d gamma = colsum(grad_out * y_hat)
+      }
     } else {
 #pragma unroll
       for (int t = 0; t < NTL; ++t) {
@@ -449,6 +490,15 @@ __global__ __launch_bounds__(NT16) void mlp_backward_stream16_kernel(const gnc_m
       }
     }
     tile = ntile;
+  }
+  if (b.ln_partial) {  // one row of partials per wave: [d beta (out_dim) | d gamma (out_dim)]
+    compiler_lds_barrier();
+    float* dst = b.ln_partial + (int64_t)((int)blockIdx.x * W16 + wave) * 2 * out_dim;
+    for (int j = lane; j < PSTRIDE; j += 64)
+      if (j < out_dim) {
+        dst[j] = lnbuf[j];
+        dst[out_dim + j] = lnbuf[PSTRIDE + j];
+      }
   }
 }
 
@@ -508,6 +558,11 @@ bool make_plan(const gnc_mlp_desc_t& d, bool want_dx, BPlan16* pl) {
 
 }  // namespace
 
+int gnc_mlp::bwd_stream16_ln_partial_rows(int64_t rows) {  // one row of LayerNorm partial sums per wave of the grid
+  const int64_t num_tiles = gnc::ceil_div(rows, (int64_t)W16 * R16);
+  return (int)(num_tiles < gnc::num_cu() ? num_tiles : gnc::num_cu()) * W16;
+}
+
 bool gnc_mlp::bwd_stream16_supported(const gnc_mlp_desc_t& d, bool want_dx) {
   BPlan16 pl;
   return make_plan(d, want_dx, &pl);
@@ -520,8 +575,10 @@ int gnc_mlp::launch_bwd_stream16(const gnc_mlp_desc_t& d, const BwdArgs& b, hipS
     return GNC_ERR_UNSUPPORTED;
   }
   constexpr int NTL = 16;
-  const size_t smem = ((size_t)NTL * 16 * LDSW + (size_t)(d.num_linear + 2) * NTL * 16 + (size_t)W16 * R16 * LDSW) * sizeof(float);
-  static_assert(((size_t)16 * 16 * LDSW + (size_t)(GNC_MAX_LINEAR + 2) * 256 + (size_t)W16 * R16 * LDSW) * sizeof(float) <= 160 * 1024,
+  const size_t smem = ((size_t)NTL * 16 * LDSW + (size_t)(d.num_linear + 2) * NTL * 16 + (size_t)W16 * R16 * LDSW +
+                       (size_t)W16 * 2 * NTL * 16) * sizeof(float);
+  static_assert(((size_t)16 * 16 * LDSW + (size_t)(GNC_MAX_LINEAR + 2) * 256 + (size_t)W16 * R16 * LDSW + (size_t)W16 * 2 * 256) *
+                        sizeof(float) <= 160 * 1024,
                 "backward16: LDS budget");
   static bool attr_set = false;
   if (!attr_set) {
