@@ -1164,8 +1164,10 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_backward_stream_kernel(const g
         {
           const int fl = fresh_lane();
           compiler_lds_barrier();
+          // residual path (the segment is also the residual): + the same columns of grad_out, read back as whole rows
+          const bool fold = b.dx_add_grad_out == s + 1;
           store_staged_rows(abuf, b.dx + d.seg[s].wcol + c0, b.ld_dx, d.seg[s].width - c0 < KC ? d.seg[s].width - c0 : KC, row0,
-                            rows, fl & 15, fl >> 4);
+                            rows, fl & 15, fl >> 4, fold ? b.grad_out + c0 : nullptr, b.ld_grad_out);
           compiler_lds_barrier();
         }
       }
@@ -1633,7 +1635,11 @@ extern "C" int gnc_mlp_backward_supported(const gnc_mlp_desc_t* fwd) {
 
 extern "C" int gnc_mlp_backward_dx_add_honoured(const gnc_mlp_desc_t* fwd) {
   int nmm, nadd, T;
-  return (fwd && validate_desc(fwd, false) == GNC_OK && bwd_shape(*fwd, &nmm, &nadd, &T)) ? 1 : 0;
+  BwdPlan pl;
+  static const bool off = getenv("GNC_NO_STREAM_DX_FOLD") != nullptr;  // A/B switch: the streaming kernels leave the add to the caller
+  if (!fwd || validate_desc(fwd, false) != GNC_OK) return 0;
+  if (bwd_shape(*fwd, &nmm, &nadd, &T)) return 1;
+  return (!off && (bwd_stream_plan(*fwd, true, &pl, &T) || use_stream16(*fwd, true))) ? 1 : 0;
 }
 
 namespace {
@@ -1730,7 +1736,13 @@ extern "C" int gnc_mlp_backward_f32(const gnc_mlp_bwd_desc_t* bd, void* stream_)
   b.dx = bd->dx;
   b.ld_dx = bd->ld_dx;
   b.yhat = d.ln_gamma ? bd->yhat : nullptr;
-  b.dx_add_grad_out = (resident && bd->dx_add_grad_out) ? 1 : 0;
+  // resident kernel: a flag (its last MATMUL segment); streaming kernels: 1 + the index of that segment
+  int last_mm = -1;
+  for (int sgi = 0; sgi < d.num_segments; ++sgi)
+    if (d.seg[sgi].mode == GNC_SEG_MATMUL) last_mm = sgi;
+  b.dx_add_grad_out = !bd->dx_add_grad_out ? 0 : resident ? 1 : last_mm + 1;
+  GNC_REQUIRE(!bd->dx_add_grad_out || (last_mm >= 0 && d.seg[last_mm].width == d.out_dim[L - 1] && !d.seg[last_mm].index),
+              "gnc_mlp_backward_f32: dx_add_grad_out needs a row-ordered last MATMUL segment as wide as the output");
   b.ln_partial = d.ln_gamma ? bd->ln_partial : nullptr;
 
   if (stream16) return launch_bwd_stream16(d, b, (hipStream_t)stream_);

@@ -484,8 +484,10 @@ __global__ __launch_bounds__(NT16) void mlp_backward_stream16_kernel(const gnc_m
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) *reinterpret_cast<f32x4*>(abuf + i * LDSW + 16 * cb + 4 * g) = dxs[cb];
         compiler_lds_barrier();
+        // residual path (the segment is also the residual): + the same columns of grad_out, read back as whole rows
+        const bool fold = b.dx_add_grad_out == s + 1;
         store_staged_rows<NP16, false>(abuf, b.dx + d.seg[s].wcol + c0, b.ld_dx, d.seg[s].width - c0 < KC ? d.seg[s].width - c0 : KC,
-                                       row0, rows, c4, rs);
+                                       row0, rows, c4, rs, fold ? b.grad_out + c0 : nullptr, b.ld_grad_out);
         compiler_lds_barrier();
       }
     }
