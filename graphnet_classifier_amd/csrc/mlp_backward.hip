@@ -489,9 +489,14 @@ __device__ __forceinline__ void xty_tile(f32x16 (&acc)[2][2], float (&csum)[2], 
   }
 }
 
-template <int NADD>
+// GG: 0 = the output gradient is grad_out's rows; 1 = those rows + the gathered rows b.gg[id of the second ADD segment]
+// (the backward of the scatter-sum that consumed the output rows, folded into this launch); 2 = the gathered rows alone
+// (grad_out is null).  Compile-time, so that every load of the tile loop stays unconditional.
+template <int NADD, int GG = 0>
 __global__ __launch_bounds__(FNT) void mlp_backward_fused_kernel(const gnc_mlp_desc_t d, const BwdArgs b, const FusedOut fo,
                                                                  const int num_wtiles) {
+  static_assert(GG == 0 || NADD == 2, "a gathered output gradient shares the ids of the second ADD segment");
+  constexpr bool HAS_G = GG != 2;  // a row-ordered grad_out exists
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int HT = 2;
   constexpr int CH = HT * 32 * LDSW;
@@ -580,10 +585,24 @@ __global__ __launch_bounds__(FNT) void mlp_backward_fused_kernel(const gnc_mlp_d
   auto load_ids = [&](int wt_) {
     if constexpr (NADD > 0) {
       int r = wt_ * RPW + (lane & 31);
-      r = r < rows ? r : rows - 1;
+      const bool inside = r < rows;
+      r = inside ? r : rows - 1;
       ids_nxt[0] = d.seg[1].index[r];
-      ids_nxt[1] = d.seg[2].index[r];
+      const int id1 = d.seg[2].index[r];
+      // with a gathered gradient (same ids) a row past the end must contribute ZEROS to grad_out, not the last row's
+      // gradient: its id points one row past the table, where the buffer window reads 0
+      ids_nxt[1] = (GG != 0 && !inside) ? (int)d.seg[2].table_rows : id1;
     }
+  };
+  // rows b.gg[id] of the gathered part of the output gradient (first out_dim columns), as whole-row pieces
+  auto gather_gg = [&](f32x4 (&dst)[NP], int id) {
+    const __amdgpu_buffer_rsrc_t w =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(b.gg), 0, (int)(uint32_t)(b.gg_rows * b.ld_gg * 4), 0x00020000);
+    const int fl = fresh_lane();
+    const int rb = id * (b.ld_gg * 4);
+    const uint32_t col = (uint32_t)((fl & 15) * 4 < out_dim ? (fl & 15) * 16 : 0);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) dst[p] = window_load(w, (uint32_t)__shfl(rb, p * 4 + (fl >> 4), 64) + col);
   };
   auto gather_rows_of = [&](f32x4 (&pa)[NADD ? NP : 1], f32x4 (&pb)[NADD ? NP : 1]) {
     if constexpr (NADD > 0) {
@@ -603,32 +622,40 @@ __global__ __launch_bounds__(FNT) void mlp_backward_fused_kernel(const gnc_mlp_d
     }
   };
   const int wt0 = (int)blockIdx.x * FWAVES + wave;
-  f32x4 pe[NP], pg[NP], pa[NADD ? NP : 1], pb[NADD ? NP : 1];
+  f32x4 pe[NP], pg[NP] = {}, pa[NADD ? NP : 1], pb[NADD ? NP : 1];  // pg stays zero without a row-ordered grad_out
   load_ids(wt0);
   ids_cur[0] = ids_nxt[0]; ids_cur[1] = ids_nxt[1];
   load_ids(wt0 + total_waves);
   load_tile_rows(pe, s0.ptr, s0.ld, wt0 * RPW, rows, e_off);   // past-the-end tiles read zeros
-  load_tile_rows(pg, b.grad_out, b.ld_grad_out, wt0 * RPW, rows, g_off);
+  if constexpr (HAS_G) load_tile_rows(pg, b.grad_out, b.ld_grad_out, wt0 * RPW, rows, g_off);
   gather_rows_of(pa, pb);
   // park a tile's rows in the wave's LDS tiles: e -> te, grad_out -> tb, the sum of the gathered projections -> ta
   auto park = [&](bool with_e) {
     if (with_e) to_tile(te, pe, s0.width);
-    to_tile(tb, pg, out_dim);
+    if constexpr (HAS_G) to_tile(tb, pg, out_dim);
+    if constexpr (NADD > 0) to_tile(ta, pa, d.seg[1].width);  // pa holds the SUM of both gathered rows by now
+  };
+  auto sum_gathered = [&]() {
     if constexpr (NADD > 0) {
 #pragma unroll
       for (int p = 0; p < NP; ++p) pa[p] += pb[p];
-      to_tile(ta, pa, d.seg[1].width);
     }
   };
+  sum_gathered();
   park(true);
   BPROBE_BEGIN();
   for (int wt = wt0; wt < num_wtiles; wt += total_waves) {
     BPROBE_TILE();
     const int row0 = wt * RPW;
     const int nrow0 = (wt + total_waves) * RPW;  // may lie past the end: windows return zeros, ids are clamped
+    int id_this = 0;  // this tile's ids of the second ADD segment (ids_cur moves on to the next tile's)
+    f32x4 pq[GG != 0 ? NP : 1];
     if constexpr (NADD > 0) {
+      if constexpr (GG != 0) id_this = ids_cur[1];
       ids_cur[0] = ids_nxt[0]; ids_cur[1] = ids_nxt[1];
       load_ids(wt + 2 * total_waves);
+      // the gathered part of this tile's output gradient lands under the forward recompute
+      if constexpr (GG != 0) gather_gg(pq, id_this);
     }
     // ---------------------------------------------------------------- forward recompute
     f32x16 a0[HT];
@@ -645,6 +672,33 @@ __global__ __launch_bounds__(FNT) void mlp_backward_fused_kernel(const gnc_mlp_d
     relu_tiles<HT>(a1);
     BPROBE(1);  // second Linear + ReLU
     // ---------------------------------------------------------------- grad of the pre-LayerNorm output
+    if constexpr (GG != 0) {  // grad_out's rows (parked in tb) + the gathered rows; GG == 2: the gathered rows alone
+      compiler_lds_barrier();
+      const int fl = fresh_lane();
+      const int c = (fl & 15) * 4;
+      float* tp = tb + (fl >> 4) * LDSW + c;
+      if (out_dim < KC) {  // wave-uniform: the full-width case carries no masks
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          f32x4 v = pq[p];
+          v.x = c + 0 < out_dim ? v.x : 0.f; v.y = c + 1 < out_dim ? v.y : 0.f;
+          v.z = c + 2 < out_dim ? v.z : 0.f; v.w = c + 3 < out_dim ? v.w : 0.f;
+          pq[p] = v;
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        if constexpr (HAS_G) pq[p] += *reinterpret_cast<const f32x4*>(tp + p * 4 * LDSW);
+        *reinterpret_cast<f32x4*>(tp + p * 4 * LDSW) = pq[p];
+      }
+      compiler_lds_barrier();
+      // both parts exist and the residual path of dx needs their sum again at the end of the tile: the summed rows go
+      // out to a scratch tensor here and come back (L2 / MALL) where grad_out's rows alone would - re-gathering there
+      // would cost a register set the kernel does not have (measured: 104 B of scratch, +0.65 ms per launch)
+      if constexpr (GG == 1) {
+        if (b.dx && b.dx_add_grad_out) store_row_pieces(pq, b.g_sum, b.ld_g_sum, out_dim, row0, rows, fl & 15, fl >> 4);
+      }
+    }
     f32x16 g[HT];
     tile_from_lds<HT>(g, tb, i, h);
     if (d.ln_gamma) {
@@ -684,7 +738,7 @@ __global__ __launch_bounds__(FNT) void mlp_backward_fused_kernel(const gnc_mlp_d
     BPROBE(4);  // da1 + mask
     // a1 is dead: the next tile's e and grad_out rows are requested here and land under layers 1 and 0
     load_tile_rows(pe, s0.ptr, s0.ld, nrow0, rows, e_off);
-    load_tile_rows(pg, b.grad_out, b.ld_grad_out, nrow0, rows, g_off);
+    if constexpr (HAS_G) load_tile_rows(pg, b.grad_out, b.ld_grad_out, nrow0, rows, g_off);
     // ---------------------------------------------------------------- layer 1
     acc_to_tile(tb, g);
     acc_to_tile(ta, a0);
@@ -704,11 +758,20 @@ __global__ __launch_bounds__(FNT) void mlp_backward_fused_kernel(const gnc_mlp_d
     acc_to_tile(tb, g);
     xty_tile(dW0, cs0, tb, te, i, h);
     to_tile(te, pe, s0.width);  // this tile's e rows are done with: the next tile's (requested two layers ago) move in
+    sum_gathered();  // the next tile's gathered rows have landed under dW0: one register set instead of two from here on
     f32x4 gres[NP];  // requested as late as the dx product still covers (L2 / MALL hits): 32 registers less under dW0
     if (b.dx && b.dx_add_grad_out) {
-      const int flg = fresh_lane();
-      load_tile_rows(gres, b.grad_out, b.ld_grad_out, row0, rows,
-                     (uint32_t)((flg >> 4) * b.ld_grad_out + ((flg & 15) * 4 < out_dim ? (flg & 15) * 4 : 0)) * 4u);
+      if constexpr (GG == 2) {
+        gather_gg(gres, id_this);
+      } else {
+        // GG == 1: the summed rows this wave stored at the top of the tile (tens of thousands of cycles ago; the explicit
+        // wait makes the read-after-write independent of that distance - every load requested so far has long landed)
+        if constexpr (GG == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const float* gsrc = GG == 1 ? b.g_sum : b.grad_out;
+        const int gld = GG == 1 ? b.ld_g_sum : b.ld_grad_out;
+        const int flg = fresh_lane();
+        load_tile_rows(gres, gsrc, gld, row0, rows, (uint32_t)((flg >> 4) * gld + ((flg & 15) * 4 < out_dim ? (flg & 15) * 4 : 0)) * 4u);
+      }
     }
     f32x16 dxs[HT];
     if (b.dx) {
@@ -721,7 +784,7 @@ __global__ __launch_bounds__(FNT) void mlp_backward_fused_kernel(const gnc_mlp_d
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       asm volatile("" ::"v"(pg[p]));
-      if constexpr (NADD > 0) asm volatile("" ::"v"(pa[p]), "v"(pb[p]));
+      if constexpr (NADD > 0) asm volatile("" ::"v"(pa[p]));
     }
     asm volatile("" ::"v"(ids_nxt[0]), "v"(ids_nxt[1]));
     // the residual path of dx BEFORE any store is issued: its grad_out rows are the youngest load, the compiler can
@@ -1664,18 +1727,18 @@ int fused_grid(int64_t rows) {
 }
 constexpr size_t kFusedSmem = ((size_t)3 * 2 * 32 * LDSW + (size_t)5 * 64 + (size_t)FWAVES * 3 * RPW * LDSW) * sizeof(float);
 
-template <int NADD>
+template <int NADD, int GG = 0>
 int launch_fused(const gnc_mlp_desc_t& d, const BwdArgs& b, const FusedOut& fo, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    int rc = gnc::check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_backward_fused_kernel<NADD>),
+    int rc = gnc::check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_backward_fused_kernel<NADD, GG>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
                             "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc) return rc;
     attr_set = true;
   }
   const int64_t num_wtiles = gnc::ceil_div(d.rows, RPW);
-  mlp_backward_fused_kernel<NADD><<<dim3((unsigned)fused_grid(d.rows)), dim3(FNT), kFusedSmem, stream>>>(d, b, fo, (int)num_wtiles);
+  mlp_backward_fused_kernel<NADD, GG><<<dim3((unsigned)fused_grid(d.rows)), dim3(FNT), kFusedSmem, stream>>>(d, b, fo, (int)num_wtiles);
   return gnc::check_launch("mlp_backward_fused_kernel");
 }
 }  // namespace
@@ -1692,10 +1755,22 @@ extern "C" int gnc_mlp_backward_f32(const gnc_mlp_bwd_desc_t* bd, void* stream_)
     if (fn < 0) { gnc::set_error("gnc_mlp_backward_f32: dw_partial given but the shape is outside the fused kernel"); return GNC_ERR_UNSUPPORTED; }
     GNC_REQUIRE(bd->dw_partial[1] && bd->dw_partial[2], "gnc_mlp_backward_f32: dw_partial[0..2] must all be given");
     GNC_REQUIRE(!d.ln_gamma || bd->ln_partial, "gnc_mlp_backward_f32: the fused kernel needs ln_partial with LayerNorm");
-    GNC_REQUIRE(bd->grad_out && bd->ld_grad_out % 4 == 0 && al16(bd->grad_out) && bd->ld_grad_out >= d.out_dim[2],
+    GNC_REQUIRE(!bd->grad_gather || gnc_mlp_backward_grad_gather_honoured(bd) == 1,
+                "gnc_mlp_backward_f32: grad_gather is not honoured for this description (gnc_mlp_backward_grad_gather_honoured)");
+    GNC_REQUIRE(bd->grad_out || bd->grad_gather, "gnc_mlp_backward_f32: grad_out is null");
+    GNC_REQUIRE(!bd->grad_out || (bd->ld_grad_out % 4 == 0 && al16(bd->grad_out) && bd->ld_grad_out >= d.out_dim[2]),
                 "gnc_mlp_backward_f32: grad_out must be 16-B aligned with ld %% 4 == 0");
     GNC_REQUIRE(!bd->dx || bd->ld_dx >= d.in_dim[0], "gnc_mlp_backward_f32: ld_dx < in_dim[0]");
     BwdArgs fb = {};
+    fb.gg = bd->grad_gather;
+    fb.gg_index = bd->grad_gather_index;
+    fb.ld_gg = bd->ld_grad_gather;
+    fb.gg_rows = bd->grad_gather_rows;
+    fb.g_sum = bd->grad_sum;
+    fb.ld_g_sum = bd->ld_grad_sum;
+    GNC_REQUIRE(!(bd->grad_gather && bd->grad_out && bd->dx && bd->dx_add_grad_out) ||
+                    (bd->grad_sum && al16(bd->grad_sum) && bd->ld_grad_sum % 4 == 0 && bd->ld_grad_sum >= d.out_dim[2]),
+                "gnc_mlp_backward_f32: grad_out + grad_gather with dx_add_grad_out needs the grad_sum scratch tensor");
     fb.grad_out = bd->grad_out;
     fb.ld_grad_out = bd->ld_grad_out;
     fb.dz[0] = bd->dz[0];
@@ -1709,8 +1784,10 @@ extern "C" int gnc_mlp_backward_f32(const gnc_mlp_bwd_desc_t* bd, void* stream_)
       fo.M[l] = d.out_dim[l];
       fo.K[l] = l == 0 ? d.seg[0].width : d.in_dim[l];
     }
+    if (fb.gg) return fb.grad_out ? launch_fused<2, 1>(d, fb, fo, (hipStream_t)stream_) : launch_fused<2, 2>(d, fb, fo, (hipStream_t)stream_);
     return fn == 2 ? launch_fused<2>(d, fb, fo, (hipStream_t)stream_) : launch_fused<0>(d, fb, fo, (hipStream_t)stream_);
   }
+  GNC_REQUIRE(!bd->grad_gather, "gnc_mlp_backward_f32: grad_gather is only honoured by the fused data + weight-gradient kernel");
   const bool resident = bwd_shape(d, &nmm, &nadd, &T);
   const bool stream32 = !resident && bwd_stream_plan(d, bd->dx != nullptr, &pl, &T);
   const bool stream16 = !resident && !stream32 && use_stream16(d, bd->dx != nullptr);
@@ -1775,6 +1852,20 @@ extern "C" int gnc_mlp_backward_f32(const gnc_mlp_bwd_desc_t* bd, void* stream_)
   if (nmm == 2) GNC_BWD(1, 2, 0);
   GNC_BWD(1, 3, 0);
 #undef GNC_BWD
+}
+
+extern "C" int gnc_mlp_backward_grad_gather_honoured(const gnc_mlp_bwd_desc_t* bd) {
+  static const bool off = getenv("GNC_NO_GRAD_GATHER_FOLD") != nullptr;  // A/B switch: the caller gathers the rows itself
+  if (off || !bd || !bd->grad_gather || !bd->grad_gather_index || !bd->dw_partial[0]) return 0;
+  const gnc_mlp_desc_t& d = bd->fwd;
+  if (validate_desc(&d, false) != GNC_OK || fused_shape(d) != 2) return 0;
+  // the fused kernel gathers with the ids of its second ADD segment (in the edge processor both are the destination)
+  if (bd->grad_gather_index != d.seg[2].index || bd->grad_gather_rows != d.seg[2].table_rows) return 0;
+  const int64_t bytes = bd->grad_gather_rows * (int64_t)bd->ld_grad_gather * 4;
+  if (bd->ld_grad_gather % 4 != 0 || !al16(bd->grad_gather) || bd->ld_grad_gather < d.out_dim[2]) return 0;
+  // ids one row past either table (rows beyond the end of the batch) must still be addressable in 32 bits
+  if (bytes + 256 > 0xffffffffll || d.seg[2].table_rows * (int64_t)d.seg[2].ld * 4 + 256 > 0xffffffffll) return 0;
+  return 1;
 }
 
 extern "C" int gnc_mlp_backward_fused_rows(const gnc_mlp_desc_t* fwd) {

@@ -747,6 +747,13 @@ struct BwdArgs {
   float* yhat;                 // [rows, out_dim] normalised pre-affine output (only with LayerNorm)
   int dx_add_grad_out;         // add grad_out rows to dx (the residual path of a segment that is also the residual)
   float* ln_partial;           // nullable: [waves, 2 * out_dim] per-wave [colsum(grad_out) | colsum(grad_out * yhat)]
+  // nullable: the gradient of output row r is (grad_out ? grad_out[r] : 0) + gg[gg_index[r]] (gnc_mlp_bwd_desc_t.grad_gather)
+  const float* gg;
+  const int* gg_index;
+  int ld_gg;
+  int64_t gg_rows;
+  float* g_sum;  // [rows, ld_g_sum] scratch for the summed rows (both parts given and dx_add_grad_out)
+  int ld_g_sum;
 };
 
 // smallest of {1,2,4,8} accumulator tiles (32 features each) covering `width`

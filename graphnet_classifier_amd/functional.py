@@ -232,19 +232,20 @@ class _EdgeProcessorWSplit(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out, grad_agg=None):
         src, dst, num_linear, activation, act_param, ln_eps, has_ln = ctx.meta
-        if ctx.with_agg:
-            # e' feeds the aggregation (its backward is a row gather by destination) AND whatever consumed e' itself:
-            # both gradients in one pass
-            if grad_agg is not None and grad_out is not None:
-                grad_out = native.gather_rows_add(grad_agg.contiguous(), dst, grad_out.contiguous())
-            elif grad_agg is not None:
-                grad_out = native.gather_rows(grad_agg.contiguous(), dst)
         need = ctx.needs_input_grad[2:]
-        if grad_out is None:
+        if not ctx.with_agg:
+            grad_agg = None
+        if grad_out is None and grad_agg is None:
             return (None, None) + tuple(None for _ in need)
-        hip = _edge_wsplit_backward_hip(ctx, grad_out) if HIP_BACKWARD else None
+        # e' feeds the aggregation (its backward is a row gather by destination: grad_agg[dst]) AND whatever consumed e'
+        # itself (grad_out): the K8 launch adds the gathered rows itself where its kernel can
+        hip = _edge_wsplit_backward_hip(ctx, grad_out, grad_agg) if HIP_BACKWARD else None
         if hip is not None:
             return (None, None) + hip
+        if grad_agg is not None and grad_out is not None:
+            grad_out = native.gather_rows_add(grad_agg.contiguous(), dst, grad_out.contiguous())
+        elif grad_agg is not None:
+            grad_out = native.gather_rows(grad_agg.contiguous(), dst)
         leaves = [a.detach().requires_grad_(bool(n)) for a, n in zip(ctx.saved_tensors, need)]
         x, e, params = leaves[0], leaves[1], leaves[2:]
         act = _torch_activation(activation, act_param)
@@ -262,7 +263,7 @@ class _EdgeProcessorWSplit(torch.autograd.Function):
         return (None, None) + tuple(next(grads) if n else None for n in need)
 
 
-def _edge_wsplit_backward_hip(ctx, grad_out):
+def _edge_wsplit_backward_hip(ctx, grad_out, grad_agg=None):
     """HIP backward of the W-split edge processor.  Per edge: the K8 data kernel (recompute + chain),
     then dz0 is (i) the gradient of both gathered projections - summed per node through the two CSRs
     (destination-sorted: the forward's; source-sorted: topo.csc) - and (ii) the left operand of dWe."""
@@ -273,7 +274,7 @@ def _edge_wsplit_backward_hip(ctx, grad_out):
     params = list(ctx.saved_tensors[2:])
     weights, biases = params[:num_linear], params[num_linear:2 * num_linear]
     ln = (params[2 * num_linear], params[2 * num_linear + 1], ln_eps) if has_ln else None
-    if topo is None or activation != "ReLU" or not grad_out.is_cuda:
+    if topo is None or activation != "ReLU" or not (grad_out if grad_out is not None else grad_agg).is_cuda:
         return None
     dn = x.size(1)
     w0 = weights[0]
@@ -287,9 +288,10 @@ def _edge_wsplit_backward_hip(ctx, grad_out):
     wl = [we_] + weights[1:]
     if not native.mlp_backward_supported(segments, wl, biases, ln, activation, e, e.size(0), modes):
         return None
-    grad_out = grad_out.contiguous()
-    r = native.mlp_backward(segments, wl, biases, ln, grad_out, rows=e.size(0), modes=modes, need_dx=bool(need[1]),
-                            residual=e)
+    r = native.mlp_backward(segments, wl, biases, ln, grad_out.contiguous() if grad_out is not None else None, rows=e.size(0),
+                            modes=modes, need_dx=bool(need[1]), residual=e,
+                            grad_gather=(grad_agg.contiguous(), dst) if grad_agg is not None else None)
+    grad_out = r["grad_out"]  # effective row-ordered gradient (None when the launch gathered part of it itself)
     dz0 = r["dz"][0]
     grads = [None] * (2 + len(params))
     if need[1]:  # through We, plus the residual path (folded into the kernel's dx when it can)

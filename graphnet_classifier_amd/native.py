@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 GNC_MAX_SEGMENTS = 4
 GNC_MAX_LINEAR = 8
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 ACTIVATIONS = {  # nn.<Name> accepted by the reference's MLP(activation=...) (models/MLP.py:21)
     "ReLU": 0, "Identity": 1, "Tanh": 2, "Sigmoid": 3, "SiLU": 4, "GELU": 5, "LeakyReLU": 6, "ELU": 7,
@@ -49,6 +49,7 @@ _SIGNATURES = {
     "gnc_sizeof_mlp_bwd_desc": (c_size_t, []),
     "gnc_mlp_backward_supported": (c_int32, [c_void_p]),
     "gnc_mlp_backward_dx_add_honoured": (c_int32, [c_void_p]),
+    "gnc_mlp_backward_grad_gather_honoured": (c_int32, [c_void_p]),
     "gnc_mlp_backward_ln_partial_rows": (c_int32, [c_void_p]),
     "gnc_mlp_backward_fused_rows": (c_int32, [c_void_p]),
     "gnc_mlp_backward_f32": (c_int32, [c_void_p, c_void_p]),
@@ -96,6 +97,8 @@ class MlpBwdDesc(Structure):
         ("act", c_void_p * GNC_MAX_LINEAR), ("dz", c_void_p * GNC_MAX_LINEAR),
         ("dx", c_void_p), ("ld_dx", c_int32), ("yhat", c_void_p), ("dx_add_grad_out", c_int32), ("ln_partial", c_void_p),
         ("dw_partial", c_void_p * GNC_MAX_LINEAR),
+        ("grad_gather", c_void_p), ("ld_grad_gather", c_int32), ("grad_gather_index", c_void_p), ("grad_gather_rows", c_int64),
+        ("grad_sum", c_void_p), ("ld_grad_sum", c_int32),
     ]
 
 
@@ -468,13 +471,19 @@ def mlp_backward_supported(segments, weights, biases, ln, activation, residual, 
     return lib.gnc_mlp_backward_supported(ctypes.byref(desc)) == 0
 
 
-def mlp_backward(segments, weights, biases, ln, grad_out: torch.Tensor, rows: int | None = None, modes=None,
-                 need_dx: bool = True, residual: torch.Tensor | None = None, fused: bool = True):
+def mlp_backward(segments, weights, biases, ln, grad_out: torch.Tensor | None, rows: int | None = None, modes=None,
+                 need_dx: bool = True, residual: torch.Tensor | None = None, fused: bool = True, grad_gather=None):
     """Data path of the MLP backward (see include/gnc_hip.h, K8).  Returns a dict with
     ``act`` (inputs of Linear 1..L-1), ``dz`` (grads of every pre-activation, dz[-1] = pre-LayerNorm),
     ``dx`` ([rows, in_dim0] in weight-column order, or None) and ``yhat`` (or None).  Shapes of the fused kernel
     (``fused=True`` and gnc_mlp_backward_fused_rows() > 0) return ``dw`` / ``db`` (one per Linear; ``dw[0]`` covers the
-    columns of the MATMUL segment) instead of ``act`` / ``dz[1:]``."""
+    columns of the MATMUL segment) instead of ``act`` / ``dz[1:]``.
+
+    ``grad_gather = (table [N, out_dim], index int32 [rows])``: the gradient of output row r is
+    ``(grad_out[r] if grad_out is not None else 0) + table[index[r]]`` - the backward of a scatter-sum that consumed the
+    output rows (models/GNN.py:99).  Kernels that honour it (gnc_mlp_backward_grad_gather_honoured) gather inside the
+    launch; otherwise the rows are gathered here first (K2).  ``r["grad_out"]`` is the effective row-ordered gradient when
+    it had to be materialised, else None."""
     lib = load_library()
     segs, w, b, residual, rows, _ = _prepare_mlp(segments, weights, biases, residual, rows, modes)
     dev = segs[0][0].device
@@ -486,19 +495,38 @@ def mlp_backward(segments, weights, biases, ln, grad_out: torch.Tensor, rows: in
     fold = (residual is not None and need_dx and mm[-1][1] is None and mm[-1][0].data_ptr() == residual.data_ptr()
             and mm[-1][2] == w[-1].size(0) and lib.gnc_mlp_backward_dx_add_honoured(ctypes.byref(bd.fwd)) == 1)
     bd.dx_add_grad_out = 1 if fold else 0
-    g = _vector_rows(_rowmajor(grad_out))
-    bd.grad_out, bd.ld_grad_out = g.data_ptr(), _ld(g)
     n_lin = len(w)
     frows = lib.gnc_mlp_backward_fused_rows(ctypes.byref(bd.fwd)) if fused else 0
+    parts = None
+    if frows > 0:
+        mk = [(w[l].size(0), w[l].size(1)) for l in range(n_lin)]
+        parts = [torch.empty(frows, m * k + m, dtype=torch.float32, device=dev) for m, k in mk]
+        for l in range(n_lin):
+            bd.dw_partial[l] = parts[l].data_ptr()
+    gt = gi = None
+    if grad_gather is not None:
+        gt, gi = _vector_rows(_rowmajor(grad_gather[0])), grad_gather[1]
+        bd.grad_gather, bd.ld_grad_gather = gt.data_ptr(), _ld(gt)
+        bd.grad_gather_index, bd.grad_gather_rows = gi.data_ptr(), gt.size(0)
+        if lib.gnc_mlp_backward_grad_gather_honoured(ctypes.byref(bd)) != 1:  # gather in front of the launch (K2)
+            grad_out = gather_rows(gt, gi) if grad_out is None else gather_rows_add(gt, gi, _rowmajor(grad_out))
+            bd.grad_gather = bd.grad_gather_index = None
+            bd.ld_grad_gather = bd.grad_gather_rows = 0
+            gt = gi = None
+    g = _vector_rows(_rowmajor(grad_out)) if grad_out is not None else None
+    if g is not None:
+        bd.grad_out, bd.ld_grad_out = g.data_ptr(), _ld(g)
+    g_sum = None
+    g_eff = g if gt is None else None   # the effective output gradient as a tensor (None: part of it is gathered in the kernel)
+    launch_ref = g if g is not None else gt
     if frows > 0:
         # fused data + weight-gradient kernel: per-wave partials of dW_l / db_l (and of the LayerNorm sums) instead of
         # the a_l / dz_l / y_hat tensors; only dz_0 (gradient of gathered ADD segments) and dx are written
         bd.dx_add_grad_out = 1 if (residual is not None and need_dx and mm[-1][1] is None
                                    and mm[-1][0].data_ptr() == residual.data_ptr() and mm[-1][2] == w[-1].size(0)) else 0
-        mk = [(w[l].size(0), w[l].size(1)) for l in range(n_lin)]
-        parts = [torch.empty(frows, m * k + m, dtype=torch.float32, device=dev) for m, k in mk]
-        for l in range(n_lin):
-            bd.dw_partial[l] = parts[l].data_ptr()
+        if gt is not None and g is not None and bd.dx_add_grad_out:  # scratch for the summed rows (see gnc_hip.h, grad_sum)
+            g_sum = torch.empty(rows, w[-1].size(0), dtype=torch.float32, device=dev)
+            bd.grad_sum, bd.ld_grad_sum = g_sum.data_ptr(), _ld(g_sum)
         dz0 = torch.empty(rows, w[0].size(0), dtype=torch.float32, device=dev) if len(segs) > 1 else None
         if dz0 is not None:
             bd.dz[0] = dz0.data_ptr()
@@ -511,8 +539,8 @@ def mlp_backward(segments, weights, biases, ln, grad_out: torch.Tensor, rows: in
             bd.ln_partial = ln_part.data_ptr()
         flops = 2.0 * rows * (3 * sum(x.size(0) * x.size(1) for x in w))
         with torch.cuda.device(dev):
-            _check(_launch(f"mlp_backward_fused_in{w[0].size(1)}_h{w[0].size(0)}_out{w[-1].size(0)}_L{n_lin}", g,
-                           lambda: lib.gnc_mlp_backward_f32(ctypes.byref(bd), _stream(g)), flops), "gnc_mlp_backward_f32")
+            _check(_launch(f"mlp_backward_fused_in{w[0].size(1)}_h{w[0].size(0)}_out{w[-1].size(0)}_L{n_lin}", launch_ref,
+                           lambda: lib.gnc_mlp_backward_f32(ctypes.byref(bd), _stream(launch_ref)), flops), "gnc_mlp_backward_f32")
         dws, dbs = [], []
         for (m, k), part in zip(mk, parts):
             tot = part.sum(dim=0)  # fixed order: reproducible
@@ -523,7 +551,7 @@ def mlp_backward(segments, weights, biases, ln, grad_out: torch.Tensor, rows: in
             tot = ln_part.sum(dim=0)
             ln_sums = (tot[:w[-1].size(0)], tot[w[-1].size(0):])
         return {"act": None, "dz": [dz0] + [None] * (n_lin - 1), "dx": dx, "yhat": None, "ln_sums": ln_sums, "dw": dws, "db": dbs,
-                "residual_folded": bool(bd.dx_add_grad_out), "_keep": (segs, w, b, g)}
+                "residual_folded": bool(bd.dx_add_grad_out), "grad_out": g_eff, "_keep": (segs, w, b, g, gt, gi, g_sum)}
     act = [torch.empty(rows, w[l].size(0), dtype=torch.float32, device=dev) for l in range(n_lin - 1)]
     dz = [torch.empty(rows, w[l].size(0), dtype=torch.float32, device=dev) for l in range(n_lin)]
     for l in range(n_lin):
@@ -550,7 +578,7 @@ def mlp_backward(segments, weights, biases, ln, grad_out: torch.Tensor, rows: in
     if ln_part is not None:
         tot = ln_part.sum(dim=0)  # fixed order: reproducible
         ln_sums = (tot[:w[-1].size(0)], tot[w[-1].size(0):])  # (d beta, d gamma)
-    return {"act": act, "dz": dz, "dx": dx, "yhat": yhat, "ln_sums": ln_sums, "residual_folded": bool(fold),
+    return {"act": act, "dz": dz, "dx": dx, "yhat": yhat, "ln_sums": ln_sums, "residual_folded": bool(fold), "grad_out": g_eff,
             "_keep": (segs, w, b, g)}
 
 

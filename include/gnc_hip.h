@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GNC_ABI_VERSION 15
+#define GNC_ABI_VERSION 16
 
 enum {
   GNC_OK = 0,
@@ -255,11 +255,29 @@ typedef struct gnc_mlp_bwd_desc {
                               receives [ dW_l row-major | db_l ] over the rows wave w processed - the layout of
                               gnc_xty_f32, formed INSIDE the data kernel.  With it act[], dz[1..], yhat are neither
                               needed nor written (dz[0] still is when given); ln_partial is required with LayerNorm. */
+  /* ABI 16: a gathered part of the output gradient.  When grad_gather is given, the gradient of output row r is
+   *   (grad_out ? grad_out[r] : 0) + grad_gather[grad_gather_index[r]]
+   * (table [grad_gather_rows, ld_grad_gather], first out_dim columns; an id outside the table contributes zeros).
+   * This is the backward of the scatter-sum that consumed the rows (models/GNN.py:99: d agg[col[e]] / d e'[e] = I)
+   * folded into the K8 launch: no [rows, out_dim] gather pass in front of it.  grad_out may then be NULL (the rows
+   * had no other consumer).  Only kernels for which gnc_mlp_backward_grad_gather_honoured() returns 1 accept it.
+   * grad_sum: device scratch [rows, ld_grad_sum >= out_dim] (16-B aligned, ld % 4 == 0), required when grad_out,
+   * grad_gather and dx_add_grad_out are all given: the kernel parks the summed rows there for the residual path of
+   * dx (contents undefined afterwards). */
+  const float* grad_gather;
+  int32_t ld_grad_gather;
+  const int32_t* grad_gather_index;
+  int64_t grad_gather_rows;
+  float* grad_sum;
+  int32_t ld_grad_sum;
 } gnc_mlp_bwd_desc_t;
 
 size_t gnc_sizeof_mlp_bwd_desc(void);
 int gnc_mlp_backward_supported(const gnc_mlp_desc_t* fwd /* host */);
 int gnc_mlp_backward_dx_add_honoured(const gnc_mlp_desc_t* fwd /* host */); /* 1 / 0 */
+/* 1 if gnc_mlp_backward_f32 accepts desc->grad_gather for this description (grad_gather* and dw_partial filled in as
+ * for the call), else 0: the caller then gathers the rows itself (gnc_gather_rows_f32 / gnc_gather_rows_add_f32) */
+int gnc_mlp_backward_grad_gather_honoured(const gnc_mlp_bwd_desc_t* desc /* host */);
 /* rows of `ln_partial` this description needs, 0 if its backward kernel cannot form the LayerNorm sums in flight */
 int gnc_mlp_backward_ln_partial_rows(const gnc_mlp_desc_t* fwd /* host */);
 /* rows of `dw_partial[l]` (and then also of `ln_partial`) if this description can run the fused data + weight-

@@ -522,6 +522,46 @@ def test_mlp_backward_kernel_matches_autograd(native, in_dims, hidden, out_dim, 
         assert float((dbeta.cpu().double() - sd64[lnk[0].replace("weight", "bias")].grad).abs().max()) < 1e-3
 
 
+@pytest.mark.parametrize("d,e,with_rows", [(64, 2111, True), (64, 2111, False), (48, 1000, True), (64, 32 * 1024 * 3 + 7, True),
+                                           (64, 32 * 1024 * 3 + 7, False), (128, 999, True), (256, 777, False)])
+def test_mlp_backward_gathered_output_gradient(native, d, e, with_rows):
+    """ABI 16: the backward of the scatter-sum that consumed the edge rows (a row gather of grad_agg by destination,
+    models/GNN.py:99) folded into the K8 launch (`grad_gather`).  The launch with the gathered part must equal the same
+    launch on the materialised gradient gather(grad_agg, dst) [+ grad_out] - bit for bit where the arithmetic is the same
+    (dz_0, weight gradients, LayerNorm sums), to rounding for dx (its residual path adds the two parts one after the other) -
+    for both forms (rows + gathered, gathered alone), a last partial tile, and the width classes whose kernels do not
+    honour the field (the binding then gathers in front of the launch)."""
+    rng = np.random.default_rng(d * 7 + e)
+    n = 301
+    sd = _mlp_sd(rng, d, d, d, 2, True)
+    t = lambda a: torch.from_numpy(a.astype(np.float32)).to(DEV)  # noqa: E731
+    ps, pd_, ea = t(rng.standard_normal((n, d))), t(rng.standard_normal((n, d))), t(rng.standard_normal((e, d)))
+    src = torch.from_numpy(rng.integers(0, n, size=e).astype(np.int32)).to(DEV)
+    dst = torch.from_numpy(np.sort(rng.integers(0, n, size=e)).astype(np.int32)).to(DEV)
+    gout = t(rng.standard_normal((e, d))) if with_rows else None
+    gagg = t(rng.standard_normal((n, d)))
+    ws = [sd[f"m.model.{i}.weight"].to(DEV) for i in (0, 2, 4)]
+    bs = [sd[f"m.model.{i}.bias"].to(DEV) for i in (0, 2, 4)]
+    ln = (sd["m.model.5.weight"].to(DEV), sd["m.model.5.bias"].to(DEV), 1e-5)
+    segs = [(ps, src), (pd_, dst), (ea, None)]
+    modes = [native.SEG_ADD, native.SEG_ADD, native.SEG_MATMUL]
+    g_eff = native.gather_rows(gagg, dst) if gout is None else native.gather_rows_add(gagg, dst, gout)
+    ref = native.mlp_backward(segs, ws, bs, ln, g_eff, rows=e, modes=modes, need_dx=True, residual=ea)
+    r = native.mlp_backward(segs, ws, bs, ln, gout, rows=e, modes=modes, need_dx=True, residual=ea, grad_gather=(gagg, dst))
+    torch.cuda.synchronize()
+    folded = r["grad_out"] is None
+    assert folded == (d <= 64 and os.environ.get("GNC_NO_GRAD_GATHER_FOLD") is None and os.environ.get("GNC_NO_FUSED_BACKWARD") is None)
+    assert r["residual_folded"] == ref["residual_folded"]
+    assert torch.equal(r["dz"][0], ref["dz"][0])
+    assert max_abs(r["dx"].cpu(), ref["dx"].cpu()) < 2e-6
+    if "dw" in ref:
+        for a, b_ in zip(r["dw"] + r["db"] + list(r["ln_sums"]), ref["dw"] + ref["db"] + list(ref["ln_sums"])):
+            assert torch.equal(a, b_)
+    # and against the definition, on the host
+    want = gagg.cpu()[dst.cpu().long()] + (gout.cpu() if gout is not None else 0)
+    assert torch.equal(g_eff.cpu(), want)
+
+
 @pytest.mark.parametrize("d", [64, 128, 256])
 def test_mlp_backward_wsplit_shape_matches_autograd(native, d):
     """The W-split edge-processor shape in the K8 data kernels of every width class (weights-resident, 32-row streamed,

@@ -15,6 +15,8 @@ from graphnet_classifier_amd import native  # noqa: E402
 dev = "cuda:0"
 n, e, d = 1_000_000, 10_000_000, 64
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+# second argument: 0 = row-ordered grad_out (default), 1 = grad_out + gathered part (ABI 16 grad_gather), 2 = gathered part alone
+gg_mode = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 g = torch.Generator().manual_seed(0)
 gsz = 160
 goe = (torch.arange(e) // (e // (n // gsz))).clamp_(max=n // gsz - 1)
@@ -23,6 +25,7 @@ dst = torch.sort(goe * gsz + torch.randint(0, gsz, (e,), generator=g))[0].int().
 ps, pd = torch.randn(n, d, device=dev), torch.randn(n, d, device=dev)
 ea = torch.randn(e, d, device=dev)
 gout = torch.randn(e, d, device=dev)
+gagg = torch.randn(n, d, device=dev)
 
 
 def lin(o, i):
@@ -37,10 +40,12 @@ ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=
 for it in range(iters):
     if it == 1:
         ev0.record()
-    r = native.mlp_backward(segs, [w0, w1, w2], [b0, b1, b2], ln, gout, rows=e, modes=modes, need_dx=True, residual=ea)
+    r = native.mlp_backward(segs, [w0, w1, w2], [b0, b1, b2], ln, None if gg_mode == 2 else gout, rows=e, modes=modes, need_dx=True,
+                            residual=ea, grad_gather=(gagg, dst) if gg_mode else None)
 ev1.record()
 torch.cuda.synchronize()
-print("ms_per_launch", ev0.elapsed_time(ev1) / (iters - 1), "fused" if "dw" in r else "split")
+print("gg_mode", gg_mode, "ms_per_launch", ev0.elapsed_time(ev1) / (iters - 1), "fused" if "dw" in r else "split",
+      "gathered in the launch" if (gg_mode and r["grad_out"] is None) else "")
 lib = native.load_library()
 if hasattr(lib, "gnc_phase_probe_bwd_read"):
     waves = 1024
