@@ -289,6 +289,30 @@ extern "C" int gnc_mlp_agg_supported(const gnc_mlp_desc_t* desc) {
   return GNC_OK;
 }
 
+// shape-only answer for the training forward's saved post-activations: the weights-resident kernel writes them
+extern "C" int gnc_mlp_save_act_supported(const gnc_mlp_desc_t* desc) {
+  int rc = validate_desc(desc, false);
+  if (rc) return rc;
+  const int L = desc->num_linear;
+  int T = tiles_for(desc->out_dim[0]);
+  const int od = desc->out_dim[L - 1];
+  const bool narrow_out = od <= 32;
+  if (!narrow_out && tiles_for(od) > T) T = tiles_for(od);
+  gnc_mlp_desc_t probe = *desc;
+  alignas(16) static float dummy_f[4];
+  for (int l = 0; l < L - 1; ++l)
+    if (!probe.save_act[l]) probe.save_act[l] = dummy_f;
+  bool ok = false;
+  rc = L >= 2 ? launch_resident(probe, T, narrow_out, nullptr, &ok, true) : GNC_OK;
+  if (rc) return rc;
+  if (!ok) {
+    gnc::set_error("gnc_mlp_save_act_supported: needs a description of the weights-resident kernel with >= 2 Linear layers and "
+                   "hidden widths that are multiples of 4");
+    return GNC_ERR_UNSUPPORTED;
+  }
+  return GNC_OK;
+}
+
 extern "C" int gnc_mlp_forward_f32(const gnc_mlp_desc_t* desc, void* stream_) {
   int rc = validate_desc(desc, true);
   if (rc) return rc;
@@ -303,6 +327,10 @@ extern "C" int gnc_mlp_forward_f32(const gnc_mlp_desc_t* desc, void* stream_) {
   bool launched = false;  // weights-resident variant first (decides by LDS fit)
   rc = launch_resident(*desc, T, narrow_out, stream, &launched);
   if (rc || launched) return rc;
+  if (desc->save_act[0]) {
+    gnc::set_error("gnc_mlp_forward_f32: save_act is not available for this description (gnc_mlp_save_act_supported)");
+    return GNC_ERR_UNSUPPORTED;
+  }
   if (desc->agg_out && T != 4 && T != 8) {
     gnc::set_error("gnc_mlp_forward_f32: the fused aggregation epilogue is not available for this description "
                    "(gnc_mlp_agg_supported)");

@@ -311,12 +311,25 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
       tiles_to_lds<HT>(hid, abuf, i, h);
     } else {
       relu_tiles<HT>(hid);
+      // training forward (gnc_mlp_desc_t.save_act): the post-activations leave as whole rows through the wave's LDS tile,
+      // which is idle between the first Linear and the epilogue (16-B pieces straight from the accumulator layout - 32 B
+      // per row and instruction - measured +0.55 ms per c3 edge launch, four times the requests at the L2)
+      auto save_rows = [&](const f32x16 (&acc)[HT], int l) {
+        compiler_lds_barrier();
+        tiles_to_lds<HT>(acc, abuf, i, h);
+        compiler_lds_barrier();
+        const int fl = fresh_lane();
+        store_staged_rows<NP, true>(abuf, d.save_act[l], d.out_dim[l], d.out_dim[l], row0, rows, fl & 15, fl >> 4);
+        compiler_lds_barrier();
+      };
+      if (d.save_act[0]) save_rows(hid, 0);
       // ---------------------------------------------------------------- hidden layers 1 .. L-2
       for (int l = 1; l < L - 1; ++l) {
         f32x16 nxt[HT];
         init_bias<HT>(nxt, pbuf + l * PSTRIDE, h);
         mma_chunk_from_regs<HT, HT>(nxt, hid, wres + (NMM + l - 1) * CH, 0, d.in_dim[l], i, h);
         relu_tiles<HT>(nxt);
+        if (d.save_act[0]) save_rows(nxt, l);
 #pragma unroll
         for (int t = 0; t < HT; ++t) hid[t] = nxt[t];
       }
@@ -489,6 +502,11 @@ int gnc_mlp::launch_resident(const gnc_mlp_desc_t& d, int T, bool narrow_out, hi
   if (nmm < 1 || nmm > 3 || (nadd != 0 && !(nadd == 2 && nmm == 1))) return GNC_OK;
   if (d.residual && (d.ld_residual % 4 != 0 || !al16(d.residual))) return GNC_OK;
   if (L > 1 && d.in_dim[1] > KC) return GNC_OK;
+  if (d.save_act[0]) {  // saved post-activations: whole rows of 16-B pieces
+    if (L < 2) return GNC_OK;
+    for (int l = 0; l < L - 1; ++l)
+      if (!d.save_act[l] || d.out_dim[l] % 4 != 0 || !al16(d.save_act[l])) return GNC_OK;
+  }
 
   const int total_chunks = nmm + (L - 1);
   const size_t floats = (size_t)total_chunks * T * 32 * LDSW + (size_t)(L + 2) * T * 32 + (size_t)RWAVES * RPW * LDSW;
@@ -498,6 +516,7 @@ int gnc_mlp::launch_resident(const gnc_mlp_desc_t& d, int T, bool narrow_out, hi
   const gnc_mlp_segment_t& lm = d.seg[nmm - 1];
   const bool resreg = d.residual && d.residual == lm.ptr && !lm.index && lm.ld == d.ld_residual && lm.width == od;
 
+  if (narrow_out && (resreg || nadd || nmm != 1)) return GNC_OK;  // out width <= 32 (the decoder): plain shapes only
   if (d.agg_out) {  // fused aggregation epilogue: the W-split edge processor shape only
     if (!(nadd == 2 && nmm == 1 && resreg && !narrow_out && d.agg_index && d.agg_fix && d.ld_agg >= od)) return GNC_OK;
     *launched = true;
@@ -515,8 +534,7 @@ int gnc_mlp::launch_resident(const gnc_mlp_desc_t& d, int T, bool narrow_out, hi
     return resreg ? launch<HT_, HT_, NMM_, NADD_, true>(d, total_chunks, smem, stream)        \
                   : launch<HT_, HT_, NMM_, NADD_, false>(d, total_chunks, smem, stream);      \
   } while (0)
-  if (narrow_out) {  // out width <= 32 (the decoder): one output tile
-    if (resreg || nadd || nmm != 1) return GNC_OK;
+  if (narrow_out) {  // one output tile
     *launched = true;
     return T == 2 ? launch<2, 1, 1, 0, false>(d, total_chunks, smem, stream)
                   : launch<1, 1, 1, 0, false>(d, total_chunks, smem, stream);

@@ -5,9 +5,10 @@ reference's only caller that needs gradients is ``utils/train_model.py:41``
 (``loss.backward()``):
 
 * scatter-sum backward is a row gather (HIP kernel K2);
-* the fused-MLP backward recomputes the small MLP with PyTorch-ROCm GPU ops and
-  differentiates that (SURVEY.md section 8 f3 lists hand-written backward kernels as the next
-  row; nothing here ever runs on the CPU).
+* the fused-MLP backward runs on the hand-written K8 kernels (every width class up to 256); the training
+  forward of the widths <= 64 kernels keeps the hidden layers' post-activations for it, the wider ones
+  recompute the forward of each tile from the inputs (``GNC_TORCH_BACKWARD=1`` switches to a PyTorch-ROCm
+  recompute for A/B runs; nothing here ever runs on the CPU).
 """
 from __future__ import annotations
 
@@ -69,11 +70,13 @@ def _torch_activation(name: str, param: float):
 
 class _MlpMeta:
     """Non-tensor arguments of one fused-MLP call."""
-    __slots__ = ("indices", "num_linear", "activation", "act_param", "ln_eps", "has_ln", "has_residual", "rows")
+    __slots__ = ("indices", "num_linear", "activation", "act_param", "ln_eps", "has_ln", "has_residual", "rows", "training")
 
     def __init__(self, indices, num_linear, activation, act_param, ln_eps, has_ln, has_residual, rows):
         self.indices, self.num_linear, self.activation, self.act_param = indices, num_linear, activation, act_param
         self.ln_eps, self.has_ln, self.has_residual, self.rows = ln_eps, has_ln, has_residual, rows
+        # the caller's grad mode (inside Function.forward it is always off): a backward can only follow when it was on
+        self.training = torch.is_grad_enabled()
 
 
 class _FusedMLP(torch.autograd.Function):
@@ -86,8 +89,11 @@ class _FusedMLP(torch.autograd.Function):
         rest = list(args[s + 2 * l:])
         ln = (rest.pop(0), rest.pop(0), meta.ln_eps) if meta.has_ln else None
         residual = rest.pop(0) if meta.has_residual else None
+        # training forward: the kernel also leaves the hidden layers' post-activations (what autograd would keep) for K8
+        ctx.acts = [] if (meta.training and any(ctx.needs_input_grad) and HIP_BACKWARD) else None
         out = native.mlp_forward(list(zip(tables, meta.indices)), list(weights), list(biases), ln=ln,
-                                 activation=meta.activation, act_param=meta.act_param, residual=residual, rows=meta.rows)
+                                 activation=meta.activation, act_param=meta.act_param, residual=residual, rows=meta.rows,
+                                 save_act=ctx.acts)
         ctx.meta = meta
         ctx.save_for_backward(*args)
         return out
@@ -97,7 +103,7 @@ class _FusedMLP(torch.autograd.Function):
         meta, args = ctx.meta, ctx.saved_tensors
         s, l = len(meta.indices), meta.num_linear
         need = ctx.needs_input_grad[1:]
-        hip = _fused_mlp_backward_hip(meta, args, need, grad_out) if HIP_BACKWARD else None
+        hip = _fused_mlp_backward_hip(meta, args, need, grad_out, ctx.acts) if HIP_BACKWARD else None
         if hip is not None:
             return (None,) + hip
         leaves = [a.detach().requires_grad_(bool(n)) for a, n in zip(args, need)]
@@ -119,7 +125,7 @@ class _FusedMLP(torch.autograd.Function):
         return (None,) + tuple(next(grads) if n else None for n in need)
 
 
-def _fused_mlp_backward_hip(meta: _MlpMeta, args, need, grad_out):
+def _fused_mlp_backward_hip(meta: _MlpMeta, args, need, grad_out, saved_act=None):
     """Backward of one fused-MLP call on the HIP kernels (K8): data path + one skinny GEMM per Linear.
     Returns the gradient tuple in argument order, or None when the shape is outside the kernels."""
     s, l = len(meta.indices), meta.num_linear
@@ -133,7 +139,7 @@ def _fused_mlp_backward_hip(meta: _MlpMeta, args, need, grad_out):
         return None
     grad_out = grad_out.contiguous()
     need_tables = any(need[:s])
-    r = native.mlp_backward(segments, weights, biases, ln, grad_out, rows=meta.rows, need_dx=need_tables)
+    r = native.mlp_backward(segments, weights, biases, ln, grad_out, rows=meta.rows, need_dx=need_tables, saved_act=saved_act)
     grads = [None] * len(args)
     # inputs: dx is in concat (= weight column) order
     off = 0
@@ -214,10 +220,14 @@ class _EdgeProcessorWSplit(torch.autograd.Function):
         w0 = weights[0]
         ps = native.mlp_forward([(x, None)], [w0[:, :dn]], [None])           # [N, H] = x Ws^T
         pd = native.mlp_forward([(x, None)], [w0[:, dn:2 * dn]], [None])     # [N, H] = x Wd^T
+        training = len(meta) > 8 and meta[8] and any(ctx.needs_input_grad) and HIP_BACKWARD
+        ctx.acts = [] if training else None   # the hidden layers' post-activations, kept for K8 where the kernel can
+        ctx.proj = (ps, pd) if training else None  # the backward's gathered inputs again: [N, H] each, kept
         out = native.mlp_forward([(ps, src), (pd, dst), (e, None)], [w0[:, 2 * dn:]] + weights[1:], biases, ln=ln,
                                  activation=activation, act_param=act_param, residual=e, rows=e.size(0),
                                  modes=[native.SEG_ADD, native.SEG_ADD, native.SEG_MATMUL],
-                                 aggregate=(topo.dst_sorted, topo.rowptr, topo.num_nodes) if with_agg else None)
+                                 aggregate=(topo.dst_sorted, topo.rowptr, topo.num_nodes) if with_agg else None,
+                                 save_act=ctx.acts)
         ctx.meta = meta[:7]
         ctx.with_agg = with_agg
         ctx.set_materialize_grads(False)  # an unused output (the last block's e') arrives as None, not as zeros
@@ -280,9 +290,12 @@ def _edge_wsplit_backward_hip(ctx, grad_out, grad_agg=None):
     w0 = weights[0]
     h = w0.size(0)
     ws_, wd_, we_ = w0[:, :dn], w0[:, dn:2 * dn], w0[:, 2 * dn:]
-    # the forward's projections are needed again as the gathered additive inputs
-    ps = native.mlp_forward([(x, None)], [ws_], [None])
-    pd = native.mlp_forward([(x, None)], [wd_], [None])
+    # the forward's projections are needed again as the gathered additive inputs (kept by the training forward)
+    if getattr(ctx, "proj", None) is not None:
+        ps, pd = ctx.proj
+    else:
+        ps = native.mlp_forward([(x, None)], [ws_], [None])
+        pd = native.mlp_forward([(x, None)], [wd_], [None])
     segments = [(ps, src), (pd, dst), (e, None)]
     modes = [native.SEG_ADD, native.SEG_ADD, native.SEG_MATMUL]
     wl = [we_] + weights[1:]
@@ -290,7 +303,8 @@ def _edge_wsplit_backward_hip(ctx, grad_out, grad_agg=None):
         return None
     r = native.mlp_backward(segments, wl, biases, ln, grad_out.contiguous() if grad_out is not None else None, rows=e.size(0),
                             modes=modes, need_dx=bool(need[1]), residual=e,
-                            grad_gather=(grad_agg.contiguous(), dst) if grad_agg is not None else None)
+                            grad_gather=(grad_agg.contiguous(), dst) if grad_agg is not None else None,
+                            saved_act=getattr(ctx, "acts", None))
     grad_out = r["grad_out"]  # effective row-ordered gradient (None when the launch gathered part of it itself)
     dz0 = r["dz"][0]
     grads = [None] * (2 + len(params))
@@ -324,7 +338,7 @@ def edge_processor_wsplit(x, e, topo, weights, biases, ln, activation="ReLU", ac
     """``with_agg=True`` returns ``(e', agg)``: the per-destination sums come from the edge launch's epilogue (or
     from K1 when that launch cannot carry it) and both outputs are differentiable."""
     meta = (topo.src_sorted, topo.dst_sorted, len(weights), activation, float(act_param),
-            float(ln[2]) if ln is not None else 0.0, ln is not None, bool(with_agg))
+            float(ln[2]) if ln is not None else 0.0, ln is not None, bool(with_agg), torch.is_grad_enabled())
     args = list(weights) + list(biases) + ([ln[0], ln[1]] if ln is not None else [])
     return _EdgeProcessorWSplit.apply(meta, topo, x, e, *args)
 

@@ -30,6 +30,7 @@ _SIGNATURES = {
     "gnc_last_error_string": (c_char_p, []),
     "gnc_target_arch": (c_char_p, []),
     "gnc_mlp_agg_supported": (c_int32, [c_void_p]),
+    "gnc_mlp_save_act_supported": (c_int32, [c_void_p]),
     "gnc_mlp_agg_fix_len": (c_int32, []),
     "gnc_agg_fixup_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p, c_int64,
                                     c_void_p]),
@@ -50,6 +51,7 @@ _SIGNATURES = {
     "gnc_mlp_backward_supported": (c_int32, [c_void_p]),
     "gnc_mlp_backward_dx_add_honoured": (c_int32, [c_void_p]),
     "gnc_mlp_backward_grad_gather_honoured": (c_int32, [c_void_p]),
+    "gnc_mlp_backward_saved_act_honoured": (c_int32, [c_void_p]),
     "gnc_mlp_backward_ln_partial_rows": (c_int32, [c_void_p]),
     "gnc_mlp_backward_fused_rows": (c_int32, [c_void_p]),
     "gnc_mlp_backward_f32": (c_int32, [c_void_p, c_void_p]),
@@ -88,6 +90,7 @@ class MlpDesc(Structure):
         ("out", c_void_p), ("ld_out", c_int32),
         ("rows", c_int64),
         ("agg_out", c_void_p), ("ld_agg", c_int32), ("agg_index", c_void_p), ("agg_fix", c_void_p),
+        ("save_act", c_void_p * GNC_MAX_LINEAR),
     ]
 
 
@@ -98,7 +101,7 @@ class MlpBwdDesc(Structure):
         ("dx", c_void_p), ("ld_dx", c_int32), ("yhat", c_void_p), ("dx_add_grad_out", c_int32), ("ln_partial", c_void_p),
         ("dw_partial", c_void_p * GNC_MAX_LINEAR),
         ("grad_gather", c_void_p), ("ld_grad_gather", c_int32), ("grad_gather_index", c_void_p), ("grad_gather_rows", c_int64),
-        ("grad_sum", c_void_p), ("ld_grad_sum", c_int32),
+        ("grad_sum", c_void_p), ("ld_grad_sum", c_int32), ("act_given", c_int32),
     ]
 
 
@@ -420,8 +423,12 @@ def _prepare_mlp(segments, weights, biases, residual, rows, modes):
     return segs, weights, biases, residual, rows, modes
 
 
+SAVE_ACT = os.environ.get("GNC_NO_SAVED_ACT") is None  # A/B switch: training forwards keep nothing, backwards recompute
+
+
 def mlp_forward(segments, weights, biases, ln=None, activation: str = "ReLU", act_param: float = 0.0,
-                residual: torch.Tensor | None = None, rows: int | None = None, modes=None, aggregate=None):
+                residual: torch.Tensor | None = None, rows: int | None = None, modes=None, aggregate=None,
+                save_act: list | None = None):
     """Fused MLP.  segments (in CONCAT order): list of (table [*, w] fp32, index int32 [rows] | None);
     ``modes[s]`` is SEG_MATMUL (default) or SEG_ADD.  Weights may be column slices of a larger
     matrix.  The segment that is also the residual is listed last for the kernel (its weight
@@ -430,12 +437,22 @@ def mlp_forward(segments, weights, biases, ln=None, activation: str = "ReLU", ac
     ``aggregate=(dst_of_row int32 [rows] non-decreasing, rowptr int32 [N+1], N)`` asks for the fused aggregation
     epilogue: returns ``(out, agg)`` with ``agg[v] = sum of out rows with dst v`` in row order,
     bit-identical to ``scatter_sum_csr(out, rowptr)``; returns ``(out, None)`` when the launch shape cannot
-    carry it (the caller then runs K1)."""
+    carry it (the caller then runs K1).
+
+    ``save_act`` (training forward): an empty list; when the kernel that serves the call can write the post-activation
+    outputs of its hidden layers (gnc_mlp_save_act_supported) they are appended to it ([rows, H] each) for
+    ``mlp_backward(saved_act=...)``, which then reads them instead of recomputing the forward of every tile."""
     lib = load_library()
     segs, weights, biases, residual, rows, modes = _prepare_mlp(segments, weights, biases, residual, rows, modes)
     dev = segs[0][0].device
     out = torch.empty(rows, weights[-1].size(0), dtype=torch.float32, device=dev)
     desc = make_mlp_desc(segs, weights, biases, ln, activation, act_param, residual, out, rows)
+    if (save_act is not None and SAVE_ACT and rows > 0 and len(weights) >= 2
+            and lib.gnc_mlp_save_act_supported(ctypes.byref(desc)) == 0):
+        for l in range(len(weights) - 1):
+            a = torch.empty(rows, weights[l].size(0), dtype=torch.float32, device=dev)
+            desc.save_act[l] = a.data_ptr()
+            save_act.append(a)
     agg = fix = None
     if aggregate is not None:
         dst_of_row, rowptr, num_nodes = aggregate
@@ -472,7 +489,8 @@ def mlp_backward_supported(segments, weights, biases, ln, activation, residual, 
 
 
 def mlp_backward(segments, weights, biases, ln, grad_out: torch.Tensor | None, rows: int | None = None, modes=None,
-                 need_dx: bool = True, residual: torch.Tensor | None = None, fused: bool = True, grad_gather=None):
+                 need_dx: bool = True, residual: torch.Tensor | None = None, fused: bool = True, grad_gather=None,
+                 saved_act=None):
     """Data path of the MLP backward (see include/gnc_hip.h, K8).  Returns a dict with
     ``act`` (inputs of Linear 1..L-1), ``dz`` (grads of every pre-activation, dz[-1] = pre-LayerNorm),
     ``dx`` ([rows, in_dim0] in weight-column order, or None) and ``yhat`` (or None).  Shapes of the fused kernel
@@ -483,7 +501,10 @@ def mlp_backward(segments, weights, biases, ln, grad_out: torch.Tensor | None, r
     ``(grad_out[r] if grad_out is not None else 0) + table[index[r]]`` - the backward of a scatter-sum that consumed the
     output rows (models/GNN.py:99).  Kernels that honour it (gnc_mlp_backward_grad_gather_honoured) gather inside the
     launch; otherwise the rows are gathered here first (K2).  ``r["grad_out"]`` is the effective row-ordered gradient when
-    it had to be materialised, else None."""
+    it had to be materialised, else None.
+
+    ``saved_act``: the list ``mlp_forward(save_act=...)`` filled for the same call; kernels that honour it
+    (gnc_mlp_backward_saved_act_honoured) read the post-activations instead of recomputing them."""
     lib = load_library()
     segs, w, b, residual, rows, _ = _prepare_mlp(segments, weights, biases, residual, rows, modes)
     dev = segs[0][0].device
@@ -503,6 +524,14 @@ def mlp_backward(segments, weights, biases, ln, grad_out: torch.Tensor | None, r
         parts = [torch.empty(frows, m * k + m, dtype=torch.float32, device=dev) for m, k in mk]
         for l in range(n_lin):
             bd.dw_partial[l] = parts[l].data_ptr()
+    if saved_act and frows > 0:
+        for l, a in enumerate(saved_act):
+            bd.act[l] = a.data_ptr()
+        bd.act_given = 1
+        if len(saved_act) != n_lin - 1 or lib.gnc_mlp_backward_saved_act_honoured(ctypes.byref(bd)) != 1:
+            for l in range(len(saved_act)):
+                bd.act[l] = None
+            bd.act_given = 0
     gt = gi = None
     if grad_gather is not None:
         gt, gi = _vector_rows(_rowmajor(grad_gather[0])), grad_gather[1]
@@ -551,7 +580,8 @@ def mlp_backward(segments, weights, biases, ln, grad_out: torch.Tensor | None, r
             tot = ln_part.sum(dim=0)
             ln_sums = (tot[:w[-1].size(0)], tot[w[-1].size(0):])
         return {"act": None, "dz": [dz0] + [None] * (n_lin - 1), "dx": dx, "yhat": None, "ln_sums": ln_sums, "dw": dws, "db": dbs,
-                "residual_folded": bool(bd.dx_add_grad_out), "grad_out": g_eff, "_keep": (segs, w, b, g, gt, gi, g_sum)}
+                "residual_folded": bool(bd.dx_add_grad_out), "grad_out": g_eff, "saved_act_used": bool(bd.act_given),
+                "_keep": (segs, w, b, g, gt, gi, g_sum, saved_act)}
     act = [torch.empty(rows, w[l].size(0), dtype=torch.float32, device=dev) for l in range(n_lin - 1)]
     dz = [torch.empty(rows, w[l].size(0), dtype=torch.float32, device=dev) for l in range(n_lin)]
     for l in range(n_lin):

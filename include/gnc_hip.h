@@ -190,6 +190,11 @@ typedef struct gnc_mlp_desc {
   int32_t ld_agg;
   const int32_t* agg_index; /* [rows] destination of each output row */
   int32_t* agg_fix;         /* [gnc_mlp_agg_fix_len()] destinations left to gnc_agg_fixup_f32 */
+  /* ABI 16, training forward: save_act[l] (l < num_linear - 1) = NULL, or [rows, out_dim[l]] contiguous: the launch
+   * also writes the post-activation output of Linear l (what torch.autograd keeps for the backward of
+   * models/MLP.py:45-47), so that gnc_mlp_backward_f32 can read it (act_given) instead of recomputing the forward of
+   * every tile.  All of them or none; only where gnc_mlp_save_act_supported() says so. */
+  float* save_act[GNC_MAX_LINEAR];
 } gnc_mlp_desc_t;
 
 /* 0 if gnc_mlp_forward_f32 can run this description, GNC_ERR_UNSUPPORTED otherwise
@@ -201,6 +206,9 @@ int gnc_mlp_forward_f32(const gnc_mlp_desc_t* desc /* host */, void* stream);
 /* fused aggregation epilogue: 0 if this description can run with agg_out set (shape fields only) */
 int gnc_mlp_agg_supported(const gnc_mlp_desc_t* desc /* host */);
 int gnc_mlp_agg_fix_len(void); /* entries of agg_fix (2 per wave of the persistent grid) */
+/* 0 if gnc_mlp_forward_f32 can run this description with save_act set (weights-resident kernel, ReLU, hidden widths
+ * that are multiples of 4), GNC_ERR_UNSUPPORTED otherwise (shape fields only) */
+int gnc_mlp_save_act_supported(const gnc_mlp_desc_t* desc /* host */);
 /* out[v, :] = sum over k in [rowptr[v], rowptr[v+1]) of src[k, :] (ascending k) for the n_fix destinations
  * v = fix[j] (entries < 0 or >= num_nodes are skipped; duplicates are harmless), and out[v, :] = 0 for every
  * destination v < num_nodes without rows: together with the epilogue every row of `out` is then defined. */
@@ -270,6 +278,10 @@ typedef struct gnc_mlp_bwd_desc {
   int64_t grad_gather_rows;
   float* grad_sum;
   int32_t ld_grad_sum;
+  /* ABI 16: 1 = act[l] (l < num_linear - 1) are INPUTS: the post-activations the forward saved (gnc_mlp_desc_t.save_act,
+   * contiguous [rows, out_dim[l]]); the kernel reads them instead of recomputing the forward of every tile.  Only where
+   * gnc_mlp_backward_saved_act_honoured() returns 1 (the fused data + weight-gradient kernel: dw_partial given). */
+  int32_t act_given;
 } gnc_mlp_bwd_desc_t;
 
 size_t gnc_sizeof_mlp_bwd_desc(void);
@@ -278,6 +290,8 @@ int gnc_mlp_backward_dx_add_honoured(const gnc_mlp_desc_t* fwd /* host */); /* 1
 /* 1 if gnc_mlp_backward_f32 accepts desc->grad_gather for this description (grad_gather* and dw_partial filled in as
  * for the call), else 0: the caller then gathers the rows itself (gnc_gather_rows_f32 / gnc_gather_rows_add_f32) */
 int gnc_mlp_backward_grad_gather_honoured(const gnc_mlp_bwd_desc_t* desc /* host */);
+/* 1 if gnc_mlp_backward_f32 accepts desc->act_given for this description (act[] and dw_partial filled in as for the call) */
+int gnc_mlp_backward_saved_act_honoured(const gnc_mlp_bwd_desc_t* desc /* host */);
 /* rows of `ln_partial` this description needs, 0 if its backward kernel cannot form the LayerNorm sums in flight */
 int gnc_mlp_backward_ln_partial_rows(const gnc_mlp_desc_t* fwd /* host */);
 /* rows of `dw_partial[l]` (and then also of `ln_partial`) if this description can run the fused data + weight-

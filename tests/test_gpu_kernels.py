@@ -562,6 +562,55 @@ def test_mlp_backward_gathered_output_gradient(native, d, e, with_rows):
     assert torch.equal(g_eff.cpu(), want)
 
 
+@pytest.mark.parametrize("d,e,nadd,gg", [(64, 2111, 2, 0), (64, 2111, 2, 1), (64, 2111, 2, 2), (48, 1000, 2, 1), (40, 333, 0, 0),
+                                         (64, 32 * 1024 * 3 + 7, 2, 1), (64, 32 * 1024 * 2 + 31, 0, 0), (64, 5, 2, 2)])
+def test_mlp_backward_saved_activations(native, d, e, nadd, gg):
+    """ABI 16: the training forward keeps the hidden layers' post-activations (`save_act`, written by the weights-resident
+    kernel straight from its accumulators) and the fused K8 kernel reads them (`act_given`) instead of recomputing the first
+    two Linear layers of every tile.  (i) the saved tensors equal the oracle's hidden activations; (ii) the backward on them
+    equals the recomputing backward - same arithmetic from there on - for the plain shape, the W-split shape and both forms
+    of the gathered output gradient, incl. a last partial tile and a batch smaller than one tile."""
+    rng = np.random.default_rng(d * 11 + e + nadd + gg)
+    n = 301
+    sd = _mlp_sd(rng, d, d, d, 2, True)
+    t = lambda a: torch.from_numpy(a.astype(np.float32)).to(DEV)  # noqa: E731
+    ea = t(rng.standard_normal((e, d)))
+    ws = [sd[f"m.model.{i}.weight"].to(DEV) for i in (0, 2, 4)]
+    bs = [sd[f"m.model.{i}.bias"].to(DEV) for i in (0, 2, 4)]
+    ln = (sd["m.model.5.weight"].to(DEV), sd["m.model.5.bias"].to(DEV), 1e-5)
+    src = torch.from_numpy(rng.integers(0, n, size=e).astype(np.int32)).to(DEV)
+    dst = torch.from_numpy(np.sort(rng.integers(0, n, size=e)).astype(np.int32)).to(DEV)
+    if nadd:
+        ps, pd_ = t(rng.standard_normal((n, d))), t(rng.standard_normal((n, d)))
+        segs, modes = [(ps, src), (pd_, dst), (ea, None)], [native.SEG_ADD, native.SEG_ADD, native.SEG_MATMUL]
+    else:
+        segs, modes = [(ea, None)], None
+    acts = []
+    out = native.mlp_forward(segs, ws, bs, ln=ln, residual=ea, rows=e, modes=modes, save_act=acts)
+    assert len(acts) == 2 and acts[0].shape == (e, d)
+    plain = native.mlp_forward(segs, ws, bs, ln=ln, residual=ea, rows=e, modes=modes)
+    assert torch.equal(out, plain)  # saving changes nothing about the output
+    z0 = ea.cpu() @ ws[0].cpu().t() + bs[0].cpu()
+    if nadd:
+        z0 = z0 + ps.cpu()[src.cpu().long()] + pd_.cpu()[dst.cpu().long()]
+    a0 = torch.relu(z0)
+    a1 = torch.relu(a0 @ ws[1].cpu().t() + bs[1].cpu())
+    assert max_abs(acts[0].cpu(), a0) < 1e-5 and max_abs(acts[1].cpu(), a1) < 1e-5
+    gout = t(rng.standard_normal((e, d))) if gg != 2 else None
+    gath = (t(rng.standard_normal((n, d))), dst) if gg else None
+    kw = dict(rows=e, modes=modes, need_dx=True, residual=ea, grad_gather=gath)
+    ref = native.mlp_backward(segs, ws, bs, ln, gout, **kw)
+    r = native.mlp_backward(segs, ws, bs, ln, gout, saved_act=acts, **kw)
+    torch.cuda.synchronize()
+    assert r["saved_act_used"] and not ref["saved_act_used"]
+    tol = 2e-6
+    if nadd:
+        assert max_abs(r["dz"][0].cpu(), ref["dz"][0].cpu()) < tol
+    assert max_abs(r["dx"].cpu(), ref["dx"].cpu()) < tol
+    for a, b_ in zip(r["dw"] + r["db"] + list(r["ln_sums"]), ref["dw"] + ref["db"] + list(ref["ln_sums"])):
+        assert float((a - b_).abs().max()) <= 1e-5 * max(1.0, float(b_.abs().max()))
+
+
 @pytest.mark.parametrize("d", [64, 128, 256])
 def test_mlp_backward_wsplit_shape_matches_autograd(native, d):
     """The W-split edge-processor shape in the K8 data kernels of every width class (weights-resident, 32-row streamed,

@@ -17,6 +17,8 @@ n, e, d = 1_000_000, 10_000_000, 64
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 # second argument: 0 = row-ordered grad_out (default), 1 = grad_out + gathered part (ABI 16 grad_gather), 2 = gathered part alone
 gg_mode = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+# third argument: 1 = the forward's saved post-activations are read (ABI 16 act_given) instead of being recomputed
+saved = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 g = torch.Generator().manual_seed(0)
 gsz = 160
 goe = (torch.arange(e) // (e // (n // gsz))).clamp_(max=n // gsz - 1)
@@ -36,22 +38,26 @@ def lin(o, i):
 ln = (torch.ones(d, device=dev), torch.zeros(d, device=dev), 1e-5)
 segs = [(ps, src), (pd, dst), (ea, None)]
 modes = [native.SEG_ADD, native.SEG_ADD, native.SEG_MATMUL]
+acts = []
+if saved:
+    native.mlp_forward(segs, [w0, w1, w2], [b0, b1, b2], ln=ln, residual=ea, rows=e, modes=modes, save_act=acts)
 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 for it in range(iters):
     if it == 1:
         ev0.record()
     r = native.mlp_backward(segs, [w0, w1, w2], [b0, b1, b2], ln, None if gg_mode == 2 else gout, rows=e, modes=modes, need_dx=True,
-                            residual=ea, grad_gather=(gagg, dst) if gg_mode else None)
+                            residual=ea, grad_gather=(gagg, dst) if gg_mode else None, saved_act=acts if saved else None)
 ev1.record()
 torch.cuda.synchronize()
-print("gg_mode", gg_mode, "ms_per_launch", ev0.elapsed_time(ev1) / (iters - 1), "fused" if "dw" in r else "split",
+print("saved_act", r["saved_act_used"], "gg_mode", gg_mode, "ms_per_launch", ev0.elapsed_time(ev1) / (iters - 1), "fused" if "dw" in r else "split",
       "gathered in the launch" if (gg_mode and r["grad_out"] is None) else "")
 lib = native.load_library()
-if hasattr(lib, "gnc_phase_probe_bwd_read"):
+reader = "gnc_phase_probe_bwd_sv_read" if saved else "gnc_phase_probe_bwd_read"
+if hasattr(lib, reader):
     waves = 1024
     buf = np.zeros(4096 * 12, dtype=np.uint64)
-    lib.gnc_phase_probe_bwd_read.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
-    lib.gnc_phase_probe_bwd_read(buf.ctypes.data, buf.nbytes)
+    getattr(lib, reader).argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    getattr(lib, reader)(buf.ctypes.data, buf.nbytes)
     b = buf.reshape(4096, 12)[:waves].astype(np.float64)
     tiles = (e + 31) // 32 / waves
     names = ["L0+add+relu", "L1+relu", "L2+LN bwd+sums", "transposes+dW2", "da1+mask", "loads+layer1", "gathers+layer0", "collect+stores+park"]
