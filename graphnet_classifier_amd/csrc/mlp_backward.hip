@@ -18,6 +18,8 @@
 //   gradients are bitwise reproducible; no atomics).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "mlp_backward_fused.h"
 
 
@@ -271,6 +273,7 @@ constexpr int SB_MAX_WCHUNKS = 64;
 struct BwdPlan {
   int num_steps;     // first-Linear staging steps per tile
   int num_wchunks;   // weight chunks per tile (forward + backward)
+  int saved;         // 1: b.act[] are the forward's saved post-activations (inputs): no forward chunks but the last Linear's
   struct { short seg, seg2, c0, add; } step[SB_MAX_STEPS];
   struct { short layer, kbase, klimit, pad; } wc[SB_MAX_WCHUNKS];
 };
@@ -291,7 +294,8 @@ __device__ __forceinline__ void mma_transposed_chunk(f32x16 (&dst)[TO], const f3
   }
 }
 
-template <int HT, int WAVES>
+// SAVED (= pl.saved, as a template flag: the run-time branch alone cost the recomputing instances 280 B of scratch)
+template <int HT, int WAVES, bool SAVED = false>
 __global__ __launch_bounds__(WAVES * 64) void mlp_backward_stream_kernel(const gnc_mlp_desc_t d, const BwdArgs b, const BwdPlan pl,
                                                                          const int num_tiles) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -425,8 +429,79 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_backward_stream_kernel(const g
   for (int tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
     const int row0 = (tile * WAVES + wave) * RPW;
 
-    // ------------------------------------------------------------------ forward recompute
+    unsigned mask[GNC_MAX_LINEAR - 1][NCH];  // ReLU masks: 32 bits per 64-column chunk and layer
+    auto relu_mask = [&](f32x16 (&acc)[HT], int l) {
+#pragma unroll
+      for (int cc = 0; cc < NCH; ++cc) {
+        unsigned m = 0;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            if (2 * cc + tt < HT) {
+              const bool pos = acc[2 * cc + tt < HT ? 2 * cc + tt : 0][r] > 0.f;
+              m |= pos ? (1u << (16 * tt + r)) : 0u;
+              acc[2 * cc + tt < HT ? 2 * cc + tt : 0][r] = pos ? acc[2 * cc + tt < HT ? 2 * cc + tt : 0][r] : 0.f;
+            }
+          }
+        mask[l][cc] = m;
+      }
+    };
+    // a [32, width] tile of a row-ordered tensor in accumulator layout, 64 columns at a time through the wave's LDS tile
+    auto load_acc_rows = [&](f32x16 (&acc)[HT], const float* base, int ld, int width) {
+#pragma unroll
+      for (int cc = 0; cc < NCH; ++cc) {
+        if (cc * KC < width) {
+          f32x4 pre[NP];
+          int r = row0 + (fresh_lane() & 31);
+          r = r < rows ? r : rows - 1;
+          load_rows(pre, base, ld, cc * KC, r);
+          stage(pre, cc * KC, width);
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt)
+            if (2 * cc + tt < HT) {
+#pragma unroll
+              for (int qq = 0; qq < 4; ++qq) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(abuf + i * LDSW + 32 * tt + 8 * qq + 4 * h);
+                const int t = 2 * cc + tt < HT ? 2 * cc + tt : 0;
+                acc[t][4 * qq + 0] = v.x; acc[t][4 * qq + 1] = v.y; acc[t][4 * qq + 2] = v.z; acc[t][4 * qq + 3] = v.w;
+              }
+            }
+          compiler_lds_barrier();
+        } else {
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt)
+            if (2 * cc + tt < HT)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[2 * cc + tt < HT ? 2 * cc + tt : 0][r] = 0.f;
+        }
+      }
+    };
+    auto apply_mask_l = [&](f32x16 (&acc)[HT], int l) {
+#pragma unroll
+      for (int cc = 0; cc < NCH; ++cc)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (2 * cc + tt < HT) {
+              const int t = 2 * cc + tt < HT ? 2 * cc + tt : 0;
+              acc[t][r] = (mask[l][cc] >> (16 * tt + r)) & 1u ? acc[t][r] : 0.f;
+            }
+    };
     f32x16 hid[HT];
+    if constexpr (SAVED) {
+      // the forward kept its post-activations (gnc_mlp_bwd_desc_t.act_given): their tiles give the ReLU masks, the last
+      // one stays in registers for the LayerNorm recompute; no forward chunk but the last Linear's is in the plan, and the
+      // weight-gradient products (gnc_xty_f32) read the saved tensors instead of copies emitted here
+#pragma unroll
+      for (int l = 0; l < GNC_MAX_LINEAR - 1; ++l)
+        if (l < L - 1) {
+          load_acc_rows(hid, b.act[l], d.out_dim[l], d.out_dim[l]);
+          relu_mask(hid, l);
+        }
+    } else {
+    // ------------------------------------------------------------------ forward recompute
     init_bias<HT>(hid, pbuf, h);
     for (int st = 0; st < pl.num_steps; ++st) {
       const int s = pl.step[st].seg, s2 = pl.step[st].seg2, c0 = pl.step[st].c0;
@@ -453,36 +528,6 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_backward_stream_kernel(const g
         publish_next_chunk();
       }
     }
-    unsigned mask[GNC_MAX_LINEAR - 1][NCH];  // ReLU masks: 32 bits per 64-column chunk and layer
-    auto relu_mask = [&](f32x16 (&acc)[HT], int l) {
-#pragma unroll
-      for (int cc = 0; cc < NCH; ++cc) {
-        unsigned m = 0;
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            if (2 * cc + tt < HT) {
-              const bool pos = acc[2 * cc + tt < HT ? 2 * cc + tt : 0][r] > 0.f;
-              m |= pos ? (1u << (16 * tt + r)) : 0u;
-              acc[2 * cc + tt < HT ? 2 * cc + tt : 0][r] = pos ? acc[2 * cc + tt < HT ? 2 * cc + tt : 0][r] : 0.f;
-            }
-          }
-        mask[l][cc] = m;
-      }
-    };
-    auto apply_mask_l = [&](f32x16 (&acc)[HT], int l) {
-#pragma unroll
-      for (int cc = 0; cc < NCH; ++cc)
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            if (2 * cc + tt < HT) {
-              const int t = 2 * cc + tt < HT ? 2 * cc + tt : 0;
-              acc[t][r] = (mask[l][cc] >> (16 * tt + r)) & 1u ? acc[t][r] : 0.f;
-            }
-    };
     relu_mask(hid, 0);
     emit(hid, b.act[0], d.out_dim[0], d.out_dim[0], row0);
 #pragma unroll
@@ -504,6 +549,7 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_backward_stream_kernel(const g
         emit(hid, b.act[l], d.out_dim[l], d.out_dim[l], row0);
       }
     }
+    }  // forward recompute
 
     // ------------------------------------------------------------------ LayerNorm recompute FIRST (the last hidden
     // activations die with it), THEN the grad_out tile: never more than two accumulator sets live
@@ -989,7 +1035,7 @@ int launch_bwd(const gnc_mlp_desc_t& d, const BwdArgs& b, int total_chunks, size
 }
 
 // plan of the streamed variant; returns false if the shape is outside it
-bool bwd_stream_plan(const gnc_mlp_desc_t& d, bool want_dx, BwdPlan* pl, int* T_out) {
+bool bwd_stream_plan(const gnc_mlp_desc_t& d, bool want_dx, BwdPlan* pl, int* T_out, bool saved = false) {
   const int L = d.num_linear;
   if (L < 2 || L > GNC_MAX_LINEAR - 1 || d.activation != GNC_ACT_RELU || d.rows >= INT32_MAX || d.rows < 1) return false;
   int wmax = 0;
@@ -1015,6 +1061,12 @@ bool bwd_stream_plan(const gnc_mlp_desc_t& d, bool want_dx, BwdPlan* pl, int* T_
   }
   if (pl->num_wchunks == 0) return false;
   const int mm_chunks = pl->num_wchunks;
+  std::remove_reference_t<decltype(pl->wc[0])> mm_wc[SB_MAX_WCHUNKS];
+  for (int k = 0; k < mm_chunks; ++k) mm_wc[k] = pl->wc[k];
+  if (saved) {  // the forward's post-activations are inputs: no chunk of the first Linear or of the hidden layers going forward
+    pl->saved = 1;
+    pl->num_wchunks = 0;
+  }
   for (int a = 0; a < nadd; a += 2) {
     const int s = add_seg[a], s2 = a + 1 < nadd ? add_seg[a + 1] : -1;
     for (int c0 = 0; c0 < d.seg[s].width; c0 += KC) {
@@ -1029,29 +1081,30 @@ bool bwd_stream_plan(const gnc_mlp_desc_t& d, bool want_dx, BwdPlan* pl, int* T_
     }
     return true;
   };
-  for (int l = 1; l < L - 1; ++l)
-    if (!push_layer(l)) return false;          // forward, hidden layers
+  if (!saved)
+    for (int l = 1; l < L - 1; ++l)
+      if (!push_layer(l)) return false;        // forward, hidden layers
   if (d.ln_gamma && !push_layer(L - 1)) return false;  // forward of the last Linear only feeds the LayerNorm statistics
   for (int l = L - 2; l >= 0; --l)
     if (!push_layer(l + 1)) return false;      // backward: W_{l+1}^T
   if (want_dx)
     for (int k = 0; k < mm_chunks; ++k) {      // dx: the first Linear's chunks again, in step order
       if (pl->num_wchunks >= SB_MAX_WCHUNKS) return false;
-      pl->wc[pl->num_wchunks] = pl->wc[k];
+      pl->wc[pl->num_wchunks] = mm_wc[k];
       ++pl->num_wchunks;
     }
   *T_out = T;
   return true;
 }
 
-template <int HT, int WAVES>
+template <int HT, int WAVES, bool SAVED = false>
 int launch_bwd_stream(const gnc_mlp_desc_t& d, const BwdArgs& b, const BwdPlan& pl, hipStream_t stream) {
   const size_t smem = ((size_t)2 * HT * 32 * LDSW + (size_t)(d.num_linear + 2) * HT * 32 + (size_t)WAVES * RPW * LDSW +
                        (size_t)WAVES * 2 * HT * 32) * sizeof(float);
   if (smem > 160 * 1024) { gnc::set_error("mlp_backward_stream: LDS budget exceeded"); return GNC_ERR_UNSUPPORTED; }
   static bool attr_set = false;
   if (!attr_set) {
-    int rc = gnc::check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_backward_stream_kernel<HT, WAVES>),
+    int rc = gnc::check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_backward_stream_kernel<HT, WAVES, SAVED>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
                             "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc) return rc;
@@ -1059,7 +1112,7 @@ int launch_bwd_stream(const gnc_mlp_desc_t& d, const BwdArgs& b, const BwdPlan& 
   }
   const int64_t num_tiles = gnc::ceil_div(d.rows, (int64_t)WAVES * RPW);
   const int64_t grid = num_tiles < gnc::num_cu() ? num_tiles : gnc::num_cu();
-  mlp_backward_stream_kernel<HT, WAVES><<<dim3((unsigned)grid), dim3(WAVES * 64), smem, stream>>>(d, b, pl, (int)num_tiles);
+  mlp_backward_stream_kernel<HT, WAVES, SAVED><<<dim3((unsigned)grid), dim3(WAVES * 64), smem, stream>>>(d, b, pl, (int)num_tiles);
   return gnc::check_launch("mlp_backward_stream_kernel");
 }
 
@@ -1161,9 +1214,11 @@ extern "C" int gnc_mlp_backward_f32(const gnc_mlp_bwd_desc_t* bd, void* stream_)
     return launch_fused_recompute(d, fb, fo, fn, (hipStream_t)stream_);
   }
   GNC_REQUIRE(!bd->grad_gather, "gnc_mlp_backward_f32: grad_gather is only honoured by the fused data + weight-gradient kernel");
-  GNC_REQUIRE(!bd->act_given, "gnc_mlp_backward_f32: act_given is only honoured by the fused data + weight-gradient kernel");
   const bool resident = bwd_shape(d, &nmm, &nadd, &T);
-  const bool stream32 = !resident && bwd_stream_plan(d, bd->dx != nullptr, &pl, &T);
+  const bool saved = bd->act_given != 0;
+  GNC_REQUIRE(!saved || gnc_mlp_backward_saved_act_honoured(bd) == 1,
+              "gnc_mlp_backward_f32: act_given is not honoured for this description (gnc_mlp_backward_saved_act_honoured)");
+  const bool stream32 = !resident && bwd_stream_plan(d, bd->dx != nullptr, &pl, &T, saved);
   const bool stream16 = !resident && !stream32 && use_stream16(d, bd->dx != nullptr);
   if (!resident && !stream32 && !stream16) {
     gnc::set_error("gnc_mlp_backward_f32: shape outside the HIP backward kernels");
@@ -1196,7 +1251,7 @@ extern "C" int gnc_mlp_backward_f32(const gnc_mlp_bwd_desc_t* bd, void* stream_)
               "gnc_mlp_backward_f32: dx_add_grad_out needs a row-ordered last MATMUL segment as wide as the output");
   b.ln_partial = d.ln_gamma ? bd->ln_partial : nullptr;
 
-  if (stream16) return launch_bwd_stream16(d, b, (hipStream_t)stream_);
+  if (stream16) return launch_bwd_stream16(d, b, (hipStream_t)stream_, saved);
   if (!resident) {
     hipStream_t st = (hipStream_t)stream_;
     switch (T) {
@@ -1204,6 +1259,10 @@ extern "C" int gnc_mlp_backward_f32(const gnc_mlp_bwd_desc_t* bd, void* stream_)
       case 2: return launch_bwd_stream<2, 4>(d, b, pl, st);
       default: {
         const int wv = bwd_stream_waves(T, d.rows);
+        if (pl.saved) {
+          if (wv == 2) return launch_bwd_stream<4, 2, true>(d, b, pl, st);
+          return wv == 4 ? launch_bwd_stream<4, 4, true>(d, b, pl, st) : launch_bwd_stream<4, 8, true>(d, b, pl, st);
+        }
         if (wv == 2) return launch_bwd_stream<4, 2>(d, b, pl, st);
         return wv == 4 ? launch_bwd_stream<4, 4>(d, b, pl, st) : launch_bwd_stream<4, 8>(d, b, pl, st);
       }
@@ -1230,12 +1289,19 @@ extern "C" int gnc_mlp_backward_f32(const gnc_mlp_bwd_desc_t* bd, void* stream_)
 
 extern "C" int gnc_mlp_backward_saved_act_honoured(const gnc_mlp_bwd_desc_t* bd) {
   static const bool off = getenv("GNC_NO_SAVED_ACT") != nullptr;  // A/B switch: the backward recomputes the forward of every tile
-  if (off || !bd || !bd->dw_partial[0]) return 0;
+  if (off || !bd) return 0;
   const gnc_mlp_desc_t& d = bd->fwd;
-  if (validate_desc(&d, false) != GNC_OK || fused_shape(d) < 0) return 0;
-  for (int l = 0; l < 2; ++l)  // contiguous [rows, out_dim[l]] rows read as 16-B pieces
+  if (validate_desc(&d, false) != GNC_OK) return 0;
+  for (int l = 0; l < d.num_linear - 1; ++l)  // contiguous [rows, out_dim[l]] rows read as 16-B pieces
     if (!bd->act[l] || !fused_al16(bd->act[l]) || d.out_dim[l] % 4 != 0) return 0;
-  return 1;
+  if (bd->dw_partial[0]) return fused_shape(d) >= 0 ? 1 : 0;  // fused data + weight-gradient kernel (widths <= 64)
+  // split path: the streaming kernels read them (and gnc_xty_f32 after them); the weights-resident data kernel recomputes
+  int nmm, nadd, T;
+  BwdPlan pl;
+  if (d.num_linear < 2 || bwd_shape(d, &nmm, &nadd, &T)) return 0;
+  // SAVED instances exist for the 65..128 class of the 32-row kernel and for the 16-row kernel (129..256)
+  if (bwd_stream_plan(d, bd->dx != nullptr, &pl, &T, true)) return T == 4 ? 1 : 0;
+  return use_stream16(d, bd->dx != nullptr) ? 1 : 0;
 }
 
 extern "C" int gnc_mlp_backward_grad_gather_honoured(const gnc_mlp_bwd_desc_t* bd) {

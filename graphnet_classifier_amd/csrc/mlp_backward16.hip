@@ -16,6 +16,8 @@
 // prefetch under the MFMAs of the previous chunk, two barriers per chunk).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "mlp_device16.h"
 
 using namespace gnc_mlp;
@@ -28,6 +30,7 @@ constexpr int B16_MAX_WCHUNKS = 72;
 struct BPlan16 {
   int num_steps;    // first-Linear staging steps per tile
   int num_wchunks;  // weight chunks per tile (forward + backward + dx)
+  int saved;        // 1: b.act[] are the forward's saved post-activations (inputs): no forward chunks but the last Linear's
   struct { short seg, c0, add, pad; } step[B16_MAX_STEPS];
   struct { short layer, kbase, klimit, pad; } wc[B16_MAX_WCHUNKS];
 };
@@ -150,7 +153,8 @@ __device__ __forceinline__ void layer_norm_backward16(f32x4 (&y)[NTL], f32x4 (&g
 }
 
 // NTL: 16-feature tiles of the widest layer (hidden / output): 16 for 129..256 features
-template <int NTL>
+// SAVED (= pl.saved, as a template flag: the run-time branch alone cost the recomputing instance 460 B of scratch)
+template <int NTL, bool SAVED = false>
 __global__ __launch_bounds__(NT16) void mlp_backward_stream16_kernel(const gnc_mlp_desc_t d, const BwdArgs b, const BPlan16 pl,
                                                                       const int num_tiles) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -302,8 +306,14 @@ __global__ __launch_bounds__(NT16) void mlp_backward_stream16_kernel(const gnc_m
     const gnc_mlp_segment_t& sg = d.seg[pl.step[st].seg];
     load_rows(pre, sg.ptr, sg.ld, sg.index, sg.table_rows, pl.step[st].c0, id_of(pl.step[st].seg), tile_of);
   };
+  // SAVED (pl.saved): the row stream of a tile is the slabs of the saved post-activations a_0 .. a_{L-2} (ReLU masks; the
+  // last tensor stays in registers for the LayerNorm recompute), then the grad_out slabs; no gathered input is read
+  auto load_first = [&](f32x4 (&pre)[NP16], int tile_of) {
+    if constexpr (SAVED) load_rows(pre, b.act[0], d.out_dim[0], nullptr, 0, 0, 0, tile_of);
+    else load_step(pre, 0, tile_of);
+  };
   f32x4 cur[NP16];
-  load_step(cur, 0, tile);
+  load_first(cur, tile);
   const int n_gslabs = (out_dim + KC - 1) / KC;
 
   while (tile < num_tiles) {
@@ -311,8 +321,36 @@ __global__ __launch_bounds__(NT16) void mlp_backward_stream16_kernel(const gnc_m
     const int ntile = tile + gridDim.x;
     int q = 0;
 
-    // ------------------------------------------------------------------ forward recompute: first Linear
     f32x4 hid[NTL];
+    unsigned mask[GNC_MAX_LINEAR - 1][MW];
+    if constexpr (SAVED) {
+#pragma unroll
+      for (int l = 0; l < GNC_MAX_LINEAR - 1; ++l) {
+        if (l < L - 1) {
+          const int width = d.out_dim[l];
+#pragma unroll
+          for (int cc = 0; cc < NCH; ++cc) {
+            if (cc * KC < width) {
+              stage(cur, cc * KC, width);
+              // the stream's next item: this tensor's next slab, the next tensor's first, or grad_out's first
+              if ((cc + 1) * KC < width) load_rows(cur, b.act[l], width, nullptr, 0, (cc + 1) * KC, 0, tile);
+              else if (l + 1 < L - 1) load_rows(cur, b.act[l + 1 < GNC_MAX_LINEAR ? l + 1 : 0], d.out_dim[l + 1 < GNC_MAX_LINEAR ? l + 1 : 0], nullptr, 0, 0, 0, tile);
+              else load_rows(cur, b.grad_out, b.ld_grad_out, nullptr, 0, 0, 0, tile);
+#pragma unroll
+              for (int cb = 0; cb < 4; ++cb)
+                if (4 * cc + cb < NTL) hid[4 * cc + cb < NTL ? 4 * cc + cb : 0] = *reinterpret_cast<const f32x4*>(abuf + i * LDSW + 16 * cb + 4 * g);
+              compiler_lds_barrier();
+            } else {
+#pragma unroll
+              for (int cb = 0; cb < 4; ++cb)
+                if (4 * cc + cb < NTL) hid[4 * cc + cb < NTL ? 4 * cc + cb : 0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+          }
+          relu_mask16<NTL>(hid, mask[l]);  // values are post-ReLU already: this only forms the bit masks
+        }
+      }
+    } else {
+    // ------------------------------------------------------------------ forward recompute: first Linear
     init_bias16<NTL>(hid, pbuf, g);
     auto stage_and_advance = [&](int st) {
       stage(cur, pl.step[st].c0, d.seg[pl.step[st].seg].width);
@@ -339,7 +377,6 @@ __global__ __launch_bounds__(NT16) void mlp_backward_stream16_kernel(const gnc_m
   }
     GNC_ADD_SLAB(0) GNC_ADD_SLAB(1) GNC_ADD_SLAB(2) GNC_ADD_SLAB(3)
 #undef GNC_ADD_SLAB
-    unsigned mask[GNC_MAX_LINEAR - 1][MW];
     relu_mask16<NTL>(hid, mask[0]);
     emit(hid, b.act[0], d.out_dim[0], d.out_dim[0], row0);
 
@@ -365,6 +402,7 @@ __global__ __launch_bounds__(NT16) void mlp_backward_stream16_kernel(const gnc_m
         emit(hid, b.act[l], d.out_dim[l], d.out_dim[l], row0);
       }
     }
+    }  // forward recompute
 
     // ------------------------------------------------------------------ grad_out tile (slab by slab), LayerNorm backward
     f32x4 gr[NTL];
@@ -380,7 +418,7 @@ __global__ __launch_bounds__(NT16) void mlp_backward_stream16_kernel(const gnc_m
             ids[k] = ids_next[k];
             if (k < d.num_segments) ids_next[k] = load_idx(ntile + (int)gridDim.x, k);
           }
-          load_step(cur, 0, ntile);
+          load_first(cur, ntile);
         }
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb)
@@ -506,7 +544,7 @@ __global__ __launch_bounds__(NT16) void mlp_backward_stream16_kernel(const gnc_m
 
 bool al16b(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-bool make_plan(const gnc_mlp_desc_t& d, bool want_dx, BPlan16* pl) {
+bool make_plan(const gnc_mlp_desc_t& d, bool want_dx, BPlan16* pl, bool saved = false) {
   const int L = d.num_linear;
   if (L < 2 || L > GNC_MAX_LINEAR - 1 || d.activation != GNC_ACT_RELU || d.rows < 1 || d.rows >= INT32_MAX - (1 << 22)) return false;
   int wmax = 0;
@@ -537,6 +575,12 @@ bool make_plan(const gnc_mlp_desc_t& d, bool want_dx, BPlan16* pl) {
     }
   if (pl->num_wchunks == 0) return false;
   const int mm_chunks = pl->num_wchunks;
+  std::remove_reference_t<decltype(pl->wc[0])> mm_wc[B16_MAX_WCHUNKS];
+  for (int k = 0; k < mm_chunks; ++k) mm_wc[k] = pl->wc[k];
+  if (saved) {  // the forward's post-activations are inputs: no chunk of the first Linear or of the hidden layers going forward
+    pl->saved = 1;
+    pl->num_wchunks = 0;
+  }
   auto push_layer = [&](int l) {
     for (int c = 0; c * KC < d.in_dim[l]; ++c) {
       if (pl->num_wchunks >= B16_MAX_WCHUNKS) return false;
@@ -544,15 +588,16 @@ bool make_plan(const gnc_mlp_desc_t& d, bool want_dx, BPlan16* pl) {
     }
     return true;
   };
-  for (int l = 1; l < L - 1; ++l)
-    if (!push_layer(l)) return false;                     // forward, hidden layers
+  if (!saved)
+    for (int l = 1; l < L - 1; ++l)
+      if (!push_layer(l)) return false;                   // forward, hidden layers
   if (d.ln_gamma && !push_layer(L - 1)) return false;     // the last Linear only feeds the LayerNorm statistics
   for (int l = L - 2; l >= 0; --l)
     if (!push_layer(l + 1)) return false;                 // backward: W_{l+1}^T
   if (want_dx)
     for (int k = 0; k < mm_chunks; ++k) {                 // dx: the first Linear's chunks again, in step order
       if (pl->num_wchunks >= B16_MAX_WCHUNKS) return false;
-      pl->wc[pl->num_wchunks] = pl->wc[k];
+      pl->wc[pl->num_wchunks] = mm_wc[k];
       ++pl->num_wchunks;
     }
   return true;
@@ -570,9 +615,9 @@ bool gnc_mlp::bwd_stream16_supported(const gnc_mlp_desc_t& d, bool want_dx) {
   return make_plan(d, want_dx, &pl);
 }
 
-int gnc_mlp::launch_bwd_stream16(const gnc_mlp_desc_t& d, const BwdArgs& b, hipStream_t stream) {
+int gnc_mlp::launch_bwd_stream16(const gnc_mlp_desc_t& d, const BwdArgs& b, hipStream_t stream, bool saved) {
   BPlan16 pl;
-  if (!make_plan(d, b.dx != nullptr, &pl)) {
+  if (!make_plan(d, b.dx != nullptr, &pl, saved)) {
     gnc::set_error("mlp_backward_stream16: shape outside the kernel");
     return GNC_ERR_UNSUPPORTED;
   }
@@ -582,16 +627,20 @@ int gnc_mlp::launch_bwd_stream16(const gnc_mlp_desc_t& d, const BwdArgs& b, hipS
   static_assert(((size_t)16 * 16 * LDSW + (size_t)(GNC_MAX_LINEAR + 2) * 256 + (size_t)W16 * R16 * LDSW + (size_t)W16 * 2 * 256) *
                         sizeof(float) <= 160 * 1024,
                 "backward16: LDS budget");
-  static bool attr_set = false;
-  if (!attr_set) {
-    int rc = gnc::check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_backward_stream16_kernel<NTL>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
-                            "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
-    if (rc) return rc;
-    attr_set = true;
-  }
   const int64_t num_tiles = gnc::ceil_div(d.rows, (int64_t)W16 * R16);
   const int64_t grid = num_tiles < gnc::num_cu() ? num_tiles : gnc::num_cu();
-  mlp_backward_stream16_kernel<NTL><<<dim3((unsigned)grid), dim3(NT16), smem, stream>>>(d, b, pl, (int)num_tiles);
+  auto go = [&](auto kernel, bool* attr_set) -> int {
+    if (!*attr_set) {
+      int rc = gnc::check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                              "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+      if (rc) return rc;
+      *attr_set = true;
+    }
+    kernel<<<dim3((unsigned)grid), dim3(NT16), smem, stream>>>(d, b, pl, (int)num_tiles);
+    return GNC_OK;
+  };
+  static bool attr_rc = false, attr_sv = false;
+  const int rc = saved ? go(&mlp_backward_stream16_kernel<NTL, true>, &attr_sv) : go(&mlp_backward_stream16_kernel<NTL, false>, &attr_rc);
+  if (rc) return rc;
   return gnc::check_launch("mlp_backward_stream16_kernel");
 }

@@ -778,6 +778,6 @@ int launch_stream16(const gnc_mlp_desc_t& d, hipStream_t stream, bool* launched,
 // K8 data kernel for widths 129..256 on 16-row tiles (mlp_backward16.hip): shape query / launch
 bool bwd_stream16_supported(const gnc_mlp_desc_t& d, bool want_dx);
 int bwd_stream16_ln_partial_rows(int64_t rows);
-int launch_bwd_stream16(const gnc_mlp_desc_t& d, const BwdArgs& b, hipStream_t stream);
+int launch_bwd_stream16(const gnc_mlp_desc_t& d, const BwdArgs& b, hipStream_t stream, bool saved = false);
 
 }  // namespace gnc_mlp

@@ -303,11 +303,22 @@ extern "C" int gnc_mlp_save_act_supported(const gnc_mlp_desc_t* desc) {
   for (int l = 0; l < L - 1; ++l)
     if (!probe.save_act[l]) probe.save_act[l] = dummy_f;
   bool ok = false;
-  rc = L >= 2 ? launch_resident(probe, T, narrow_out, nullptr, &ok, true) : GNC_OK;
-  if (rc) return rc;
+  if (L >= 2) {  // the dispatch chain of gnc_mlp_forward_f32: resident, 16-row streaming (129..256), 32-row streaming
+    rc = launch_resident(probe, T, narrow_out, nullptr, &ok, true);
+    if (rc) return rc;
+    static const bool s16_128 = getenv("GNC_STREAM16_D128") != nullptr;
+    if (!ok && (T == 8 || (T == 4 && s16_128 && !probe.agg_out))) {
+      rc = launch_stream16(probe, nullptr, &ok, true);
+      if (rc) return rc;
+    }
+    if (!ok) {
+      rc = launch_stream(probe, T, narrow_out, nullptr, &ok, true);
+      if (rc) return rc;
+    }
+  }
   if (!ok) {
-    gnc::set_error("gnc_mlp_save_act_supported: needs a description of the weights-resident kernel with >= 2 Linear layers and "
-                   "hidden widths that are multiples of 4");
+    gnc::set_error("gnc_mlp_save_act_supported: needs >= 2 Linear layers with ReLU, hidden widths that are multiples of 4 "
+                   "(at most 256) and aligned tables (the generic kernel does not write them)");
     return GNC_ERR_UNSUPPORTED;
   }
   return GNC_OK;
@@ -327,10 +338,6 @@ extern "C" int gnc_mlp_forward_f32(const gnc_mlp_desc_t* desc, void* stream_) {
   bool launched = false;  // weights-resident variant first (decides by LDS fit)
   rc = launch_resident(*desc, T, narrow_out, stream, &launched);
   if (rc || launched) return rc;
-  if (desc->save_act[0]) {
-    gnc::set_error("gnc_mlp_forward_f32: save_act is not available for this description (gnc_mlp_save_act_supported)");
-    return GNC_ERR_UNSUPPORTED;
-  }
   if (desc->agg_out && T != 4 && T != 8) {
     gnc::set_error("gnc_mlp_forward_f32: the fused aggregation epilogue is not available for this description "
                    "(gnc_mlp_agg_supported)");
@@ -351,6 +358,10 @@ extern "C" int gnc_mlp_forward_f32(const gnc_mlp_desc_t* desc, void* stream_) {
   if (desc->agg_out) {
     gnc::set_error("gnc_mlp_forward_f32: the fused aggregation epilogue is not available for this description "
                    "(gnc_mlp_agg_supported)");
+    return GNC_ERR_UNSUPPORTED;
+  }
+  if (desc->save_act[0]) {
+    gnc::set_error("gnc_mlp_forward_f32: save_act is not available for this description (gnc_mlp_save_act_supported)");
     return GNC_ERR_UNSUPPORTED;
   }
 

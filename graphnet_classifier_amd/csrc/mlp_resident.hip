@@ -79,7 +79,9 @@ constexpr int RNT = RWAVES * 64;
 // carries the running sum of the destination in progress from tile to tile in one register (lane = feature),
 // so a destination's rows are added in ascending order exactly as K1 does; only the first and the last
 // destination of a wave's range (which may continue in a neighbour's range) are left to gnc_agg_fixup_f32.
-template <int HT, int OT, int NMM, int NADD, bool RESREG, bool AGG = false>
+// SAVE: training forward (gnc_mlp_desc_t.save_act): the hidden layers' post-activations are also written.  A template
+// flag, not a run-time test: the mere presence of the branch cost the inference forward 1.3 % at c3 (same-box A/B).
+template <int HT, int OT, int NMM, int NADD, bool RESREG, bool AGG = false, bool SAVE = false>
 __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t d, const int num_wtiles,
                                                            const int total_chunks) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -322,14 +324,14 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
         store_staged_rows<NP, true>(abuf, d.save_act[l], d.out_dim[l], d.out_dim[l], row0, rows, fl & 15, fl >> 4);
         compiler_lds_barrier();
       };
-      if (d.save_act[0]) save_rows(hid, 0);
+      if constexpr (SAVE) save_rows(hid, 0);
       // ---------------------------------------------------------------- hidden layers 1 .. L-2
       for (int l = 1; l < L - 1; ++l) {
         f32x16 nxt[HT];
         init_bias<HT>(nxt, pbuf + l * PSTRIDE, h);
         mma_chunk_from_regs<HT, HT>(nxt, hid, wres + (NMM + l - 1) * CH, 0, d.in_dim[l], i, h);
         relu_tiles<HT>(nxt);
-        if (d.save_act[0]) save_rows(nxt, l);
+        if constexpr (SAVE) save_rows(nxt, l);
 #pragma unroll
         for (int t = 0; t < HT; ++t) hid[t] = nxt[t];
       }
@@ -450,12 +452,12 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
   PROBE_END();
 }
 
-template <int HT, int OT, int NMM, int NADD, bool RESREG, bool AGG = false>
+template <int HT, int OT, int NMM, int NADD, bool RESREG, bool AGG = false, bool SAVE = false>
 int launch(const gnc_mlp_desc_t& d, int total_chunks, size_t smem, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
     int rc = gnc::check_hip(
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_resident_kernel<HT, OT, NMM, NADD, RESREG, AGG>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_resident_kernel<HT, OT, NMM, NADD, RESREG, AGG, SAVE>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
         "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc) return rc;
@@ -465,7 +467,7 @@ int launch(const gnc_mlp_desc_t& d, int total_chunks, size_t smem, hipStream_t s
   int64_t grid = gnc::ceil_div(num_wtiles, RWAVES);
   if (grid > gnc::num_cu()) grid = gnc::num_cu();  // one persistent workgroup per CU
   if constexpr (AGG) grid = gnc::num_cu();        // agg_fix has two entries for every wave of the full grid
-  mlp_resident_kernel<HT, OT, NMM, NADD, RESREG, AGG>
+  mlp_resident_kernel<HT, OT, NMM, NADD, RESREG, AGG, SAVE>
       <<<dim3((unsigned)grid), dim3(RNT), smem, stream>>>(d, (int)num_wtiles, total_chunks);
   return gnc::check_launch("mlp_resident_kernel");
 }
@@ -517,6 +519,19 @@ int gnc_mlp::launch_resident(const gnc_mlp_desc_t& d, int T, bool narrow_out, hi
   const bool resreg = d.residual && d.residual == lm.ptr && !lm.index && lm.ld == d.ld_residual && lm.width == od;
 
   if (narrow_out && (resreg || nadd || nmm != 1)) return GNC_OK;  // out width <= 32 (the decoder): plain shapes only
+  if (d.save_act[0]) {
+    // training forward: SAVE instances exist for the shapes whose K8 kernel reads the saved tensors (the fused data +
+    // weight-gradient kernel: widths 33..64, ONE row-ordered MATMUL segment, 0 or 2 gathered ADD segments)
+    if (T != 2 || narrow_out || nmm != 1 || L < 2) return GNC_OK;
+    if (d.agg_out && !(nadd == 2 && resreg && d.agg_index && d.agg_fix && d.ld_agg >= od)) return GNC_OK;
+    if (nadd == 2 && !resreg) return GNC_OK;
+    *launched = true;
+    if (probe_only) return GNC_OK;
+    if (d.agg_out) return launch<2, 2, 1, 2, true, true, true>(d, total_chunks, smem, stream);
+    if (nadd == 2) return launch<2, 2, 1, 2, true, false, true>(d, total_chunks, smem, stream);
+    return resreg ? launch<2, 2, 1, 0, true, false, true>(d, total_chunks, smem, stream)
+                  : launch<2, 2, 1, 0, false, false, true>(d, total_chunks, smem, stream);
+  }
   if (d.agg_out) {  // fused aggregation epilogue: the W-split edge processor shape only
     if (!(nadd == 2 && nmm == 1 && resreg && !narrow_out && d.agg_index && d.agg_fix && d.ld_agg >= od)) return GNC_OK;
     *launched = true;

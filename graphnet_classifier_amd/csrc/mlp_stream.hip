@@ -49,7 +49,8 @@ struct StreamPlan {
 // of 32-row tiles and carries the running sum of the destination in progress, one register per 64 output columns;
 // a workgroup still steps through the weight chunks in lockstep, so waves whose range is one tile shorter run a
 // last iteration on a tile past the table's end (loads return zeros / clamped rows, stores are dropped).
-template <int HT, int OT, int WAVES, bool DBUF, bool ADD2, bool AGG = false>
+// SAVE: training forward (gnc_mlp_desc_t.save_act): the hidden layers' post-activations are also written
+template <int HT, int OT, int WAVES, bool DBUF, bool ADD2, bool AGG = false, bool SAVE = false>
 __global__ __launch_bounds__(WAVES * 64) void mlp_stream_kernel(const gnc_mlp_desc_t d, const StreamPlan pl,
                                                                 const int num_tiles) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -308,6 +309,29 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_stream_kernel(const gnc_mlp_de
       if (d.ln_gamma) layer_norm_tiles<HT>(hid, pbuf + L * PSTRIDE, pbuf + (L + 1) * PSTRIDE, out_dim, d.ln_eps, h);
     } else {
       relu_tiles<HT>(hid);
+      // training forward (gnc_mlp_desc_t.save_act): the post-activations leave as whole rows, 64 columns at a time
+      // through the wave's LDS tile (idle between the first Linear's staging and the epilogue)
+      auto save_rows = [&](const f32x16 (&acc)[HT], int l) {
+        const int width = d.out_dim[l];
+#pragma unroll
+        for (int cc = 0; cc < (HT + 1) / 2; ++cc) {
+          if (cc * KC < width) {
+            compiler_lds_barrier();
+            switch (cc) {
+              case 0: chunk_to_lds<HT, 0>(acc, abuf, i, h); break;
+              case 1: chunk_to_lds<HT, 2>(acc, abuf, i, h); break;
+              case 2: chunk_to_lds<HT, 4>(acc, abuf, i, h); break;
+              default: chunk_to_lds<HT, 6>(acc, abuf, i, h); break;
+            }
+            compiler_lds_barrier();
+            const int fl = fresh_lane();
+            store_staged_rows<NP, true>(abuf, d.save_act[l] + cc * KC, width, width - cc * KC < KC ? width - cc * KC : KC, row0, rows,
+                                        fl & 15, fl >> 4);
+            compiler_lds_barrier();
+          }
+        }
+      };
+      if constexpr (SAVE) save_rows(hid, 0);
       // ---------------------------------------------------------------- hidden layers 1 .. L-2
       for (int l = 1; l < L - 1; ++l) {
         f32x16 (&nxt)[HT] = reinterpret_cast<f32x16 (&)[HT]>(acc2);
@@ -324,6 +348,7 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_stream_kernel(const gnc_mlp_de
         relu_tiles<HT>(nxt);
 #pragma unroll
         for (int t = 0; t < HT; ++t) hid[t] = nxt[t];
+        if constexpr (SAVE) save_rows(hid, l);
       }
     }
 
@@ -437,7 +462,7 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_stream_kernel(const gnc_mlp_de
   }
 }
 
-template <int HT, int OT, int WAVES, bool DBUF, bool ADD2, bool AGG = false>
+template <int HT, int OT, int WAVES, bool DBUF, bool ADD2, bool AGG = false, bool SAVE = false>
 int launch(const gnc_mlp_desc_t& d, const StreamPlan& pl, hipStream_t stream) {
   constexpr int WT = HT > OT ? HT : OT;
   const size_t smem =
@@ -448,7 +473,7 @@ int launch(const gnc_mlp_desc_t& d, const StreamPlan& pl, hipStream_t stream) {
   }
   static bool attr_set = false;
   if (!attr_set) {
-    int rc = gnc::check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_stream_kernel<HT, OT, WAVES, DBUF, ADD2, AGG>),
+    int rc = gnc::check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_stream_kernel<HT, OT, WAVES, DBUF, ADD2, AGG, SAVE>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
                             "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc) return rc;
@@ -457,7 +482,7 @@ int launch(const gnc_mlp_desc_t& d, const StreamPlan& pl, hipStream_t stream) {
   const int64_t num_tiles = gnc::ceil_div(d.rows, (int64_t)WAVES * RPW);
   int64_t grid = num_tiles < gnc::num_cu() ? num_tiles : gnc::num_cu();  // one persistent workgroup per CU
   if constexpr (AGG) grid = gnc::num_cu();  // agg_fix has two entries for every wave of the full grid (8 waves per workgroup)
-  mlp_stream_kernel<HT, OT, WAVES, DBUF, ADD2, AGG><<<dim3((unsigned)grid), dim3(WAVES * 64), smem, stream>>>(d, pl, (int)num_tiles);
+  mlp_stream_kernel<HT, OT, WAVES, DBUF, ADD2, AGG, SAVE><<<dim3((unsigned)grid), dim3(WAVES * 64), smem, stream>>>(d, pl, (int)num_tiles);
   return gnc::check_launch("mlp_stream_kernel");
 }
 
@@ -473,6 +498,11 @@ int gnc_mlp::launch_stream(const gnc_mlp_desc_t& d, int T, bool narrow_out, hipS
   const int L = d.num_linear;
   if (L > 1 && d.activation != GNC_ACT_RELU) return GNC_OK;
   if (d.residual && (d.ld_residual % 4 != 0 || !al16(d.residual))) return GNC_OK;
+  if (d.save_act[0]) {  // saved post-activations: whole rows of 16-B pieces
+    if (L < 2) return GNC_OK;
+    for (int l = 0; l < L - 1; ++l)
+      if (!d.save_act[l] || d.out_dim[l] % 4 != 0 || !al16(d.save_act[l])) return GNC_OK;
+  }
   for (int l = 0; l < L; ++l)
     if (ldw_of(d, l) % 4 != 0 || !al16(d.weight[l])) return GNC_OK;
 
@@ -506,16 +536,22 @@ int gnc_mlp::launch_stream(const gnc_mlp_desc_t& d, int T, bool narrow_out, hipS
       pl.wc[pl.num_wchunks++] = {(short)l, (short)(c * KC), (short)d.in_dim[l], 0};
     }
 
+  const bool save = d.save_act[0] != nullptr;  // training forward: SAVE instances of the 128-wide kernel (a template flag:
+  if (save && (T != 4 || narrow_out)) return GNC_OK;  // the run-time branch alone cost the c2 inference forward 6 %)
   if (d.agg_out) {  // fused aggregation epilogue: the 128-wide instance, whole 16-B output pieces
     const int od = d.out_dim[L - 1];
     if (!(T == 4 && !narrow_out && od % 4 == 0 && d.ld_out % 4 == 0 && al16(d.out) && d.agg_index && d.agg_fix && d.ld_agg >= od))
       return GNC_OK;
     *launched = true;
     if (probe_only) return GNC_OK;
-    return launch<4, 4, 8, true, false, true>(d, pl, stream);
+    return save ? launch<4, 4, 8, true, false, true, true>(d, pl, stream) : launch<4, 4, 8, true, false, true>(d, pl, stream);
   }
   *launched = true;
   if (probe_only) return GNC_OK;
+  if (save) {
+    const bool small_rows = d.rows <= (int64_t)2 * RPW * gnc::num_cu();
+    return small_rows ? launch<4, 4, 2, true, false, false, true>(d, pl, stream) : launch<4, 4, 8, true, false, false, true>(d, pl, stream);
+  }
   // Small batches (the reference's own regime: ONE ~1000-node graph per call, main.py:60): with 8-wave workgroups a
   // 2,000-row launch is 8 workgroups, each streaming the whole weight sequence with nothing to overlap it (38 us per
   // forward launch, 145 us per backward launch in the captured training step's trace).  2-wave workgroups spread the

@@ -33,7 +33,8 @@ struct Plan16 {
 // CONTIGUOUS range of 16-row wave tiles and carries the running sum of the destination in progress, one register per 64
 // output columns; the workgroup still steps through the weight chunks in lockstep, so waves whose range is one tile
 // shorter run a last iteration on a tile past the table's end (loads return zeros / clamped rows, stores are dropped).
-template <int NTH, int NTO, bool DBUF, bool AGG = false>
+// SAVE: training forward (gnc_mlp_desc_t.save_act): the hidden layers' post-activations are also written
+template <int NTH, int NTO, bool DBUF, bool AGG = false, bool SAVE = false>
 __global__ __launch_bounds__(NT16) void mlp_stream16_kernel(const gnc_mlp_desc_t d, const Plan16 pl, const int num_tiles) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int NTW = NTH > NTO ? NTH : NTO;
@@ -272,6 +273,26 @@ __global__ __launch_bounds__(NT16) void mlp_stream16_kernel(const gnc_mlp_desc_t
       }
     } else {
       relu16<NTH>(hid);
+      // training forward (gnc_mlp_desc_t.save_act): the post-activations leave as whole rows, 64 columns at a time
+      // through the wave's LDS tile (idle between the first Linear's staging and the epilogue)
+      auto save_rows = [&](const f32x4 (&acc)[NTH], int l) {
+        const int width = d.out_dim[l];
+#pragma unroll
+        for (int cc = 0; cc < (NTH + 3) / 4; ++cc) {
+          if (cc * KC < width) {
+            compiler_lds_barrier();
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+              if (4 * cc + cb < NTH) *reinterpret_cast<f32x4*>(abuf + i * LDSW + 16 * cb + 4 * g) = acc[4 * cc + cb < NTH ? 4 * cc + cb : 0];
+            compiler_lds_barrier();
+            const int fl = fresh_lane();
+            store_staged_rows<NP16, true>(abuf, d.save_act[l] + cc * KC, width, width - cc * KC < KC ? width - cc * KC : KC, row0, rows,
+                                          fl & 15, fl >> 4);
+            compiler_lds_barrier();
+          }
+        }
+      };
+      if constexpr (SAVE) save_rows(hid, 0);
       for (int l = 1; l < L - 1; ++l) {
         f32x4 nxt[NTH];
         init_bias16<NTH>(nxt, pbuf + l * PSTRIDE, g);
@@ -289,6 +310,7 @@ __global__ __launch_bounds__(NT16) void mlp_stream16_kernel(const gnc_mlp_desc_t
         relu16<NTH>(nxt);
 #pragma unroll
         for (int t = 0; t < NTH; ++t) hid[t] = nxt[t];
+        if constexpr (SAVE) save_rows(hid, l);
       }
       init_bias16<NTO>(o, pbuf + (L - 1) * PSTRIDE, g);
 #define GNC_OUT_CHUNK(C_)                                                                          \
@@ -394,7 +416,7 @@ __global__ __launch_bounds__(NT16) void mlp_stream16_kernel(const gnc_mlp_desc_t
   }
 }
 
-template <int NTH, int NTO, bool AGG = false>
+template <int NTH, int NTO, bool AGG = false, bool SAVE = false>
 int launch16(const gnc_mlp_desc_t& d, const Plan16& pl, hipStream_t stream) {
   constexpr int NTW = NTH > NTO ? NTH : NTO;
   constexpr bool DBUF = NTW <= 8;
@@ -406,7 +428,7 @@ int launch16(const gnc_mlp_desc_t& d, const Plan16& pl, hipStream_t stream) {
   }
   static bool attr_set = false;
   if (!attr_set) {
-    int rc = gnc::check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_stream16_kernel<NTH, NTO, DBUF, AGG>),
+    int rc = gnc::check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_stream16_kernel<NTH, NTO, DBUF, AGG, SAVE>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
                             "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc) return rc;
@@ -415,7 +437,7 @@ int launch16(const gnc_mlp_desc_t& d, const Plan16& pl, hipStream_t stream) {
   const int64_t num_tiles = gnc::ceil_div(d.rows, (int64_t)W16 * R16);
   int64_t grid = num_tiles < gnc::num_cu() ? num_tiles : gnc::num_cu();
   if constexpr (AGG) grid = gnc::num_cu();  // agg_fix has two entries for every wave of the full grid (8 waves per workgroup)
-  mlp_stream16_kernel<NTH, NTO, DBUF, AGG><<<dim3((unsigned)grid), dim3(NT16), smem, stream>>>(d, pl, (int)num_tiles);
+  mlp_stream16_kernel<NTH, NTO, DBUF, AGG, SAVE><<<dim3((unsigned)grid), dim3(NT16), smem, stream>>>(d, pl, (int)num_tiles);
   return gnc::check_launch("mlp_stream16_kernel");
 }
 
@@ -432,6 +454,11 @@ int gnc_mlp::launch_stream16(const gnc_mlp_desc_t& d, hipStream_t stream, bool* 
   const int H = d.out_dim[0], od = d.out_dim[L - 1];
   if (H > 256 || od > 256) return GNC_OK;
   if (d.residual && (d.ld_residual % 4 != 0 || !al16p(d.residual))) return GNC_OK;
+  if (d.save_act[0]) {  // saved post-activations: whole rows of 16-B pieces
+    if (L < 2) return GNC_OK;
+    for (int l = 0; l < L - 1; ++l)
+      if (!d.save_act[l] || d.out_dim[l] % 4 != 0 || !al16p(d.save_act[l])) return GNC_OK;
+  }
   for (int l = 0; l < L; ++l)
     if (ldw_of(d, l) % 4 != 0 || !al16p(d.weight[l])) return GNC_OK;
   Plan16 pl = {};
@@ -458,14 +485,17 @@ int gnc_mlp::launch_stream16(const gnc_mlp_desc_t& d, hipStream_t stream, bool* 
       if (pl.num_wchunks >= MAX_WCHUNKS16) return GNC_OK;
       pl.wc[pl.num_wchunks++] = {(short)l, (short)(c * KC), (short)d.in_dim[l], 0};
     }
+  const bool save = d.save_act[0] != nullptr;  // training forward: SAVE instances of the 256-wide kernel (template flag)
+  if (save && !(H > 128 && od > 16)) return GNC_OK;
   if (d.agg_out) {  // aggregation epilogue: the 256-wide instance only (129..256 output features), rows < 2^31 / 16
     if (!(od > 128 && L > 1) || !d.agg_index || !d.agg_fix || d.ld_agg < od) return GNC_OK;
     *launched = true;
     if (probe_only) return GNC_OK;
-    return launch16<16, 16, true>(d, pl, stream);
+    return save ? launch16<16, 16, true, true>(d, pl, stream) : launch16<16, 16, true>(d, pl, stream);
   }
   *launched = true;
   if (probe_only) return GNC_OK;
+  if (save) return launch16<16, 16, false, true>(d, pl, stream);
   if (H <= 128 && od <= 128) {
     if (od <= 16 && L > 1) return launch16<8, 1>(d, pl, stream);
     return launch16<8, 8>(d, pl, stream);

@@ -426,6 +426,21 @@ def _prepare_mlp(segments, weights, biases, residual, rows, modes):
 SAVE_ACT = os.environ.get("GNC_NO_SAVED_ACT") is None  # A/B switch: training forwards keep nothing, backwards recompute
 
 
+def _backward_reads_saved_act(lib, desc, any_tensor) -> bool:
+    """Would gnc_mlp_backward_f32 read saved post-activations for this description?  (Shape question only: the K8 kernel
+    of some shapes - the weights-resident data kernel of the node processors - recomputes regardless, and a forward that
+    saved for it would write tensors nobody reads.)"""
+    bd = MlpBwdDesc()
+    ctypes.memmove(ctypes.byref(bd.fwd), ctypes.byref(desc), ctypes.sizeof(MlpDesc))
+    ptr = any_tensor.data_ptr()  # any 16-B aligned device address: the query looks at alignment only
+    for l in range(desc.num_linear - 1):
+        bd.act[l] = ptr
+    bd.act_given, bd.dx = 1, ptr
+    if lib.gnc_mlp_backward_fused_rows(ctypes.byref(bd.fwd)) > 0:
+        bd.dw_partial[0] = ptr
+    return lib.gnc_mlp_backward_saved_act_honoured(ctypes.byref(bd)) == 1
+
+
 def mlp_forward(segments, weights, biases, ln=None, activation: str = "ReLU", act_param: float = 0.0,
                 residual: torch.Tensor | None = None, rows: int | None = None, modes=None, aggregate=None,
                 save_act: list | None = None):
@@ -448,7 +463,7 @@ def mlp_forward(segments, weights, biases, ln=None, activation: str = "ReLU", ac
     out = torch.empty(rows, weights[-1].size(0), dtype=torch.float32, device=dev)
     desc = make_mlp_desc(segs, weights, biases, ln, activation, act_param, residual, out, rows)
     if (save_act is not None and SAVE_ACT and rows > 0 and len(weights) >= 2
-            and lib.gnc_mlp_save_act_supported(ctypes.byref(desc)) == 0):
+            and lib.gnc_mlp_save_act_supported(ctypes.byref(desc)) == 0 and _backward_reads_saved_act(lib, desc, out)):
         for l in range(len(weights) - 1):
             a = torch.empty(rows, weights[l].size(0), dtype=torch.float32, device=dev)
             desc.save_act[l] = a.data_ptr()
@@ -524,14 +539,16 @@ def mlp_backward(segments, weights, biases, ln, grad_out: torch.Tensor | None, r
         parts = [torch.empty(frows, m * k + m, dtype=torch.float32, device=dev) for m, k in mk]
         for l in range(n_lin):
             bd.dw_partial[l] = parts[l].data_ptr()
-    if saved_act and frows > 0:
+    if saved_act:
         for l, a in enumerate(saved_act):
             bd.act[l] = a.data_ptr()
         bd.act_given = 1
+        bd.dx = 1 if need_dx else None  # (the query looks at whether dx is wanted; the real pointer follows below)
         if len(saved_act) != n_lin - 1 or lib.gnc_mlp_backward_saved_act_honoured(ctypes.byref(bd)) != 1:
             for l in range(len(saved_act)):
                 bd.act[l] = None
             bd.act_given = 0
+        bd.dx = None
     gt = gi = None
     if grad_gather is not None:
         gt, gi = _vector_rows(_rowmajor(grad_gather[0])), grad_gather[1]
@@ -582,7 +599,8 @@ def mlp_backward(segments, weights, biases, ln, grad_out: torch.Tensor | None, r
         return {"act": None, "dz": [dz0] + [None] * (n_lin - 1), "dx": dx, "yhat": None, "ln_sums": ln_sums, "dw": dws, "db": dbs,
                 "residual_folded": bool(bd.dx_add_grad_out), "grad_out": g_eff, "saved_act_used": bool(bd.act_given),
                 "_keep": (segs, w, b, g, gt, gi, g_sum, saved_act)}
-    act = [torch.empty(rows, w[l].size(0), dtype=torch.float32, device=dev) for l in range(n_lin - 1)]
+    # split path: the data kernel emits a_l (unless the forward saved them: act_given) and dz_l for gnc_xty_f32
+    act = list(saved_act) if bd.act_given else [torch.empty(rows, w[l].size(0), dtype=torch.float32, device=dev) for l in range(n_lin - 1)]
     dz = [torch.empty(rows, w[l].size(0), dtype=torch.float32, device=dev) for l in range(n_lin)]
     for l in range(n_lin):
         bd.dz[l] = dz[l].data_ptr()
@@ -609,7 +627,7 @@ def mlp_backward(segments, weights, biases, ln, grad_out: torch.Tensor | None, r
         tot = ln_part.sum(dim=0)  # fixed order: reproducible
         ln_sums = (tot[:w[-1].size(0)], tot[w[-1].size(0):])  # (d beta, d gamma)
     return {"act": act, "dz": dz, "dx": dx, "yhat": yhat, "ln_sums": ln_sums, "residual_folded": bool(fold), "grad_out": g_eff,
-            "_keep": (segs, w, b, g)}
+            "saved_act_used": bool(bd.act_given), "_keep": (segs, w, b, g)}
 
 
 def _xty_spans(n: int, step: int):

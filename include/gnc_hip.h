@@ -206,8 +206,8 @@ int gnc_mlp_forward_f32(const gnc_mlp_desc_t* desc /* host */, void* stream);
 /* fused aggregation epilogue: 0 if this description can run with agg_out set (shape fields only) */
 int gnc_mlp_agg_supported(const gnc_mlp_desc_t* desc /* host */);
 int gnc_mlp_agg_fix_len(void); /* entries of agg_fix (2 per wave of the persistent grid) */
-/* 0 if gnc_mlp_forward_f32 can run this description with save_act set (weights-resident kernel, ReLU, hidden widths
- * that are multiples of 4), GNC_ERR_UNSUPPORTED otherwise (shape fields only) */
+/* 0 if gnc_mlp_forward_f32 can run this description with save_act set (every kernel but the generic fallback: ReLU, hidden
+ * widths that are multiples of 4 and at most 256, aligned tables), GNC_ERR_UNSUPPORTED otherwise (shape fields only) */
 int gnc_mlp_save_act_supported(const gnc_mlp_desc_t* desc /* host */);
 /* out[v, :] = sum over k in [rowptr[v], rowptr[v+1]) of src[k, :] (ascending k) for the n_fix destinations
  * v = fix[j] (entries < 0 or >= num_nodes are skipped; duplicates are harmless), and out[v, :] = 0 for every

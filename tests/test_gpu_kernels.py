@@ -563,7 +563,9 @@ def test_mlp_backward_gathered_output_gradient(native, d, e, with_rows):
 
 
 @pytest.mark.parametrize("d,e,nadd,gg", [(64, 2111, 2, 0), (64, 2111, 2, 1), (64, 2111, 2, 2), (48, 1000, 2, 1), (40, 333, 0, 0),
-                                         (64, 32 * 1024 * 3 + 7, 2, 1), (64, 32 * 1024 * 2 + 31, 0, 0), (64, 5, 2, 2)])
+                                         (64, 32 * 1024 * 3 + 7, 2, 1), (64, 32 * 1024 * 2 + 31, 0, 0), (64, 5, 2, 2),
+                                         (128, 2111, 2, 0), (128, 70001, 2, 1), (100, 999, 0, 0), (96, 1500, 2, 2),
+                                         (256, 2111, 2, 0), (256, 40001, 2, 1), (200, 999, 0, 0), (192, 700, 2, 2), (132, 300, 2, 0)])
 def test_mlp_backward_saved_activations(native, d, e, nadd, gg):
     """ABI 16: the training forward keeps the hidden layers' post-activations (`save_act`, written by the weights-resident
     kernel straight from its accumulators) and the fused K8 kernel reads them (`act_given`) instead of recomputing the first
@@ -603,12 +605,31 @@ def test_mlp_backward_saved_activations(native, d, e, nadd, gg):
     r = native.mlp_backward(segs, ws, bs, ln, gout, saved_act=acts, **kw)
     torch.cuda.synchronize()
     assert r["saved_act_used"] and not ref["saved_act_used"]
-    tol = 2e-6
+    tol = 1e-5  # the forward's saved a_l and the recomputed ones differ by rounding (summation order of the first Linear)
+    # ... and a pre-activation within rounding of 0 may land on either side of the ReLU in the two runs: that row's
+    # gradients then differ legitimately (the derivative is not defined there).  At most a couple of rows per case.
+    odd = torch.zeros(e, dtype=torch.bool)
+
+    def close_rows(a, b_):
+        nonlocal odd
+        bad = (a.cpu() - b_.cpu()).abs().amax(dim=1) >= tol
+        odd |= bad
+
     if nadd:
-        assert max_abs(r["dz"][0].cpu(), ref["dz"][0].cpu()) < tol
-    assert max_abs(r["dx"].cpu(), ref["dx"].cpu()) < tol
-    for a, b_ in zip(r["dw"] + r["db"] + list(r["ln_sums"]), ref["dw"] + ref["db"] + list(ref["ln_sums"])):
-        assert float((a - b_).abs().max()) <= 1e-5 * max(1.0, float(b_.abs().max()))
+        close_rows(r["dz"][0], ref["dz"][0])
+    close_rows(r["dx"], ref["dx"])
+    if "dw" not in ref:  # split path (streaming kernels): the data kernel hands the SAVED tensors on to the weight-gradient products
+        assert all(a.data_ptr() == s_.data_ptr() for a, s_ in zip(r["act"], acts))
+        for a, b_ in zip(r["dz"], ref["dz"]):
+            close_rows(a, b_)
+        for a, b_ in zip(r["act"], ref["act"]):  # what the recomputing kernel emits = what the forward saved
+            assert max_abs(a.cpu(), b_.cpu()) < tol
+    assert int(odd.sum()) <= 2, int(odd.sum())
+    wtol = 1e-5 if not odd.any() else 1e-2  # sums over the rows: a flipped row moves them by about its own gradient
+    sums_r = (r["dw"] + r["db"] if "dw" in r else []) + list(r["ln_sums"])
+    sums_ref = (ref["dw"] + ref["db"] if "dw" in ref else []) + list(ref["ln_sums"])
+    for a, b_ in zip(sums_r, sums_ref):
+        assert float((a - b_).abs().max()) <= wtol * max(1.0, float(b_.abs().max()))
 
 
 @pytest.mark.parametrize("d", [64, 128, 256])
