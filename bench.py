@@ -120,6 +120,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scale", type=float, default=1.0,
                     help="fraction of the workload's graphs (tests / rehearsals only; the contract number is --scale 1)")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="forward mode: replay the step (CSR build + forward) from ONE hipGraph captured after the warm-up instead "
+                         "of enqueueing its ~40 launches from Python every step.  auto = on for N > 1 (a 1/8 shard of c3 is 1.3 ms "
+                         "of kernels behind 1.5 ms of host enqueue: tools/host_profile.py), off at N = 1 (GPU-bound either way, and "
+                         "the per-launch HIP events of the roofline objects then live inside the timed region)")
     ap.add_argument("--mode", default="forward", choices=["forward", "train"],
                     help="train: the timed step is forward + cross-entropy + backward (HIP K8 kernels) + one flat gradient "
                          "all-reduce (RCCL, world > 1) + fused Adam, graphs batched block-diagonally")
@@ -246,7 +251,27 @@ def main():
     steps_seen = max(1, a.warmup + (int(n_heat.item()) + 1 if a.preheat_ms > 0 else 0))
     timers.reserve(int(warm_timers.num_launches() / steps_seen * (a.steps + 1) * 1.1) + 64)
     del warm_timers
-    native.set_kernel_timers(timers)
+    # hipGraph replay of the step (see --graph): captured once, after the warm-up; any failure falls back to eager launches
+    graph, graph_out, graph_note = None, None, None
+    if a.mode == "forward" and (a.graph == "on" or (a.graph == "auto" and world > 1)):
+        native.set_kernel_timers(None)  # HIP events per launch cannot be recorded into a capture
+        torch.cuda.synchronize()
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                graph_out = step()
+            graph.replay()
+            torch.cuda.synchronize()
+        except Exception as ex:  # noqa: BLE001 - whatever the runtime refuses: measure the eager step instead
+            graph, graph_out, graph_note = None, None, f"capture failed, eager launches used: {ex}"
+            torch.cuda.synchronize()
+    run_step = step
+    if graph is not None:
+        def run_step():
+            graph.replay()
+            return graph_out
+    else:
+        native.set_kernel_timers(timers)
     fence()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]  # per-step spread (diagnostic only)
     for ev in marks:
@@ -256,10 +281,17 @@ def main():
     t0 = time.perf_counter()
     marks[0].record()
     for k in range(a.steps):
-        y = step()
+        y = run_step()
         marks[k + 1].record()
     fence()
     elapsed = time.perf_counter() - t0
+    ksteps = a.steps  # steps behind the per-kernel HIP events
+    if graph is not None:  # ... which cannot live inside a replay: the same step, eagerly, right after the timed region
+        native.set_kernel_timers(timers)
+        ksteps = min(a.steps, 10)
+        for _ in range(ksteps):
+            step()
+        fence()
     topology.check_deferred()  # the out-of-range flags of every timed step, read with one sync (raises IndexError if set)
     y_fwd = y
     device_allocs_timed = torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - allocs0
@@ -409,9 +441,13 @@ def main():
             "step_ms_spread": {"min": per_step[0], "median": per_step[len(per_step) // 2], "max": per_step[-1],
                                "slowest_step": per_step_order.index(per_step[-1]),
                                "device_allocs_in_timed_region": device_allocs_timed},
-            "kernel_ms_per_step": {k: v["avg_ms"] * v["launches"] / a.steps for k, v in ksum.items()
+            "kernel_ms_per_step": {k: v["avg_ms"] * v["launches"] / ksteps for k, v in ksum.items()
                                    if not (k1_isolated and k.startswith("scatter_sum_csr"))},
         }
+        if a.mode == "forward":
+            result["step_launch"] = (f"one hipGraph replay per step (captured after the warm-up; per-kernel HIP events from {ksteps} eager "
+                                     "steps after the timed region)") if graph is not None else \
+                                    ("eager launches from Python" + (f" ({graph_note})" if graph_note else ""))
         if train_steps:
             result["train"] = {
                 "step": "CSR build + forward + CE loss + backward + gradient pack + ONE flat all-reduce (world > 1) + fused Adam",

@@ -434,6 +434,8 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(tmp_path):
         assert d["scaling"] == scaling
         if scaling == "strong":
             assert d["config"]["workload"].startswith("c4:"), d["config"]["workload"]
+        if "--mode" not in extra:  # N > 1: the forward step is replayed from one hipGraph (small shards are launch-bound)
+            assert d["step_launch"].startswith("one hipGraph replay"), d["step_launch"]
         tr = d["train"]
         assert tr["collectives_per_step"] == 1.0 and tr["allreduce_ms"] > 0 and tr["value"] > 0
         assert tr["allreduce_bytes"] >= 4 * 60_000
