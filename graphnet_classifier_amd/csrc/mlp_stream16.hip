@@ -12,6 +12,8 @@
 // 70 KB buffer: two do not fit next to the row tiles); rows are staged 16 per wave.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "mlp_device16.h"
 
 using namespace gnc_mlp;
@@ -273,26 +275,24 @@ __global__ __launch_bounds__(NT16) void mlp_stream16_kernel(const gnc_mlp_desc_t
       }
     } else {
       relu16<NTH>(hid);
-      // training forward (gnc_mlp_desc_t.save_act): the post-activations leave as whole rows, 64 columns at a time
-      // through the wave's LDS tile (idle between the first Linear's staging and the epilogue)
-      auto save_rows = [&](const f32x4 (&acc)[NTH], int l) {
+      // training forward (gnc_mlp_desc_t.save_act): the INPUT of the layer being computed leaves as whole rows, one 64-column
+      // slab next to each of that layer's weight chunks (through the wave's LDS tile, idle between the first Linear's
+      // staging and the epilogue).  All slabs of a tensor in one go right after its ReLU measured +1.7 ms per c5 edge
+      // launch, +0.15 ms of it the LDS transposes: the 8 waves of all 256 CUs run in step, the burst (33 MB chip-wide)
+      // takes longer to drain than the next chunk's MFMAs last, and the next weight chunk's vmcnt wait sits it out.
+      auto save_slab = [&](const f32x4 (&acc)[NTH], int l, auto cc_) {
+        constexpr int cc = decltype(cc_)::value;
         const int width = d.out_dim[l];
+        compiler_lds_barrier();
 #pragma unroll
-        for (int cc = 0; cc < (NTH + 3) / 4; ++cc) {
-          if (cc * KC < width) {
-            compiler_lds_barrier();
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb)
-              if (4 * cc + cb < NTH) *reinterpret_cast<f32x4*>(abuf + i * LDSW + 16 * cb + 4 * g) = acc[4 * cc + cb < NTH ? 4 * cc + cb : 0];
-            compiler_lds_barrier();
-            const int fl = fresh_lane();
-            store_staged_rows<NP16, true>(abuf, d.save_act[l] + cc * KC, width, width - cc * KC < KC ? width - cc * KC : KC, row0, rows,
-                                          fl & 15, fl >> 4);
-            compiler_lds_barrier();
-          }
-        }
+        for (int cb = 0; cb < 4; ++cb)
+          if (4 * cc + cb < NTH) *reinterpret_cast<f32x4*>(abuf + i * LDSW + 16 * cb + 4 * g) = acc[4 * cc + cb < NTH ? 4 * cc + cb : 0];
+        compiler_lds_barrier();
+        const int fl = fresh_lane();
+        store_staged_rows<NP16, true>(abuf, d.save_act[l] + cc * KC, width, width - cc * KC < KC ? width - cc * KC : KC, row0, rows,
+                                      fl & 15, fl >> 4);
+        compiler_lds_barrier();
       };
-      if constexpr (SAVE) save_rows(hid, 0);
       for (int l = 1; l < L - 1; ++l) {
         f32x4 nxt[NTH];
         init_bias16<NTH>(nxt, pbuf + l * PSTRIDE, g);
@@ -300,6 +300,7 @@ __global__ __launch_bounds__(NT16) void mlp_stream16_kernel(const gnc_mlp_desc_t
   if constexpr (C_ < NCHI) {                                                                     \
     if (C_ * KC < d.in_dim[l]) {                                                                 \
       prefetch_next_chunk(q);                                                                    \
+      if constexpr (SAVE) save_slab(hid, l - 1, std::integral_constant<int, C_>{});               \
       mma16_chunk_from_regs<NTH, NTH, C_>(nxt, hid, cur_w(), d.in_dim[l], i, g);   \
       publish_next_chunk();                                                                      \
       ++q;                                                                                       \
@@ -310,13 +311,13 @@ __global__ __launch_bounds__(NT16) void mlp_stream16_kernel(const gnc_mlp_desc_t
         relu16<NTH>(nxt);
 #pragma unroll
         for (int t = 0; t < NTH; ++t) hid[t] = nxt[t];
-        if constexpr (SAVE) save_rows(hid, l);
       }
       init_bias16<NTO>(o, pbuf + (L - 1) * PSTRIDE, g);
 #define GNC_OUT_CHUNK(C_)                                                                          \
   if constexpr (C_ < NCHI) {                                                                       \
     if (C_ * KC < d.in_dim[L - 1]) {                                                               \
       prefetch_next_chunk(q);                                                                      \
+      if constexpr (SAVE) save_slab(hid, L - 2, std::integral_constant<int, C_>{});                 \
       mma16_chunk_from_regs<NTH, NTO, C_>(o, hid, cur_w(), d.in_dim[L - 1], i, g);   \
       publish_next_chunk();                                                                        \
       ++q;                                                                                         \
