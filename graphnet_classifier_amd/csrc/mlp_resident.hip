@@ -81,7 +81,10 @@ constexpr int RNT = RWAVES * 64;
 // destination of a wave's range (which may continue in a neighbour's range) are left to gnc_agg_fixup_f32.
 // SAVE: training forward (gnc_mlp_desc_t.save_act): the hidden layers' post-activations are also written.  A template
 // flag, not a run-time test: the mere presence of the branch cost the inference forward 1.3 % at c3 (same-box A/B).
-template <int HT, int OT, int NMM, int NADD, bool RESREG, bool AGG = false, bool SAVE = false>
+// FULL: every width of the launch is exactly 64 (segments, hidden layers, output), three Linear layers, LayerNorm, vector
+// output rows - the c3 edge processor.  The general instance keeps ~40 loop-invariant lane masks (feature / column < width)
+// and the dimensions themselves alive across the tile loop; here they are compile-time constants.
+template <int HT, int OT, int NMM, int NADD, bool RESREG, bool AGG = false, bool SAVE = false, bool FULL = false>
 __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t d, const int num_wtiles,
                                                            const int total_chunks) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -96,8 +99,8 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
   const int h = lane >> 5;
   const int c4 = lane & 15;
   const int rs = lane >> 4;
-  const int L = d.num_linear;
-  const int out_dim = d.out_dim[L - 1];
+  const int L = FULL ? 3 : d.num_linear;
+  const int out_dim = FULL ? KC : d.out_dim[L - 1];
   const int rows = (int)d.rows;
   float* wres = lds;
   float* pbuf = lds + total_chunks * CH;
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
 
   SegView sv[NS];
 #pragma unroll
-  for (int s = 0; s < NS; ++s) sv[s] = {d.seg[s].ptr, d.seg[s].index, d.seg[s].ld, d.seg[s].width,
+  for (int s = 0; s < NS; ++s) sv[s] = {d.seg[s].ptr, d.seg[s].index, d.seg[s].ld, FULL ? KC : d.seg[s].width,
                                           (uint32_t)(d.seg[s].table_rows * d.seg[s].ld * 4)};  // launcher: < 4 GiB
 
   // ---- per-wave pipeline -----------------------------------------------------------------------
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
   uint32_t off0 = row_offset(wt + stride, sv[0]);
 
   const int col_out = c4 * 4;
-  const bool vec_out = (out_dim % 4 == 0) && (d.ld_out % 4 == 0) && ((reinterpret_cast<uintptr_t>(d.out) & 15u) == 0);
+  const bool vec_out = FULL || ((out_dim % 4 == 0) && (d.ld_out % 4 == 0) && ((reinterpret_cast<uintptr_t>(d.out) & 15u) == 0));
   const uint32_t out_lane_off = (uint32_t)(rs * d.ld_out + col_out) * 4u;
   const uint32_t res_lane_off = (uint32_t)(rs * d.ld_residual + (col_out < d.ld_residual ? col_out : 0)) * 4u;
 
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
       for (int l = 1; l < L - 1; ++l) {
         f32x16 nxt[HT];
         init_bias<HT>(nxt, pbuf + l * PSTRIDE, h);
-        mma_chunk_from_regs<HT, HT>(nxt, hid, wres + (NMM + l - 1) * CH, 0, d.in_dim[l], i, h);
+        mma_chunk_from_regs<HT, HT>(nxt, hid, wres + (NMM + l - 1) * CH, 0, FULL ? KC : d.in_dim[l], i, h);
         relu_tiles<HT>(nxt);
         if constexpr (SAVE) save_rows(nxt, l);
 #pragma unroll
@@ -339,9 +342,9 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
       // ---------------------------------------------------------------- last Linear, LayerNorm
       f32x16 o[OT];
       init_bias<OT>(o, pbuf + (L - 1) * PSTRIDE, h);
-      mma_chunk_from_regs<HT, OT>(o, hid, wres + (NMM + L - 2) * CH, 0, d.in_dim[L - 1], i, h);
+      mma_chunk_from_regs<HT, OT>(o, hid, wres + (NMM + L - 2) * CH, 0, FULL ? KC : d.in_dim[L - 1], i, h);
       PROBE(4);  // last Linear
-      if (d.ln_gamma) layer_norm_tiles<OT>(o, pbuf + L * PSTRIDE, pbuf + (L + 1) * PSTRIDE, out_dim, d.ln_eps, h);
+      if (FULL || d.ln_gamma) layer_norm_tiles<OT>(o, pbuf + L * PSTRIDE, pbuf + (L + 1) * PSTRIDE, out_dim, d.ln_eps, h);
       if constexpr (RESREG) {
 #pragma unroll
         for (int t = 0; t < OT && t < HT; ++t) o[t] += res[t < HT ? t : 0];
@@ -452,12 +455,12 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
   PROBE_END();
 }
 
-template <int HT, int OT, int NMM, int NADD, bool RESREG, bool AGG = false, bool SAVE = false>
+template <int HT, int OT, int NMM, int NADD, bool RESREG, bool AGG = false, bool SAVE = false, bool FULL = false>
 int launch(const gnc_mlp_desc_t& d, int total_chunks, size_t smem, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
     int rc = gnc::check_hip(
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_resident_kernel<HT, OT, NMM, NADD, RESREG, AGG, SAVE>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_resident_kernel<HT, OT, NMM, NADD, RESREG, AGG, SAVE, FULL>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
         "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc) return rc;
@@ -467,7 +470,7 @@ int launch(const gnc_mlp_desc_t& d, int total_chunks, size_t smem, hipStream_t s
   int64_t grid = gnc::ceil_div(num_wtiles, RWAVES);
   if (grid > gnc::num_cu()) grid = gnc::num_cu();  // one persistent workgroup per CU
   if constexpr (AGG) grid = gnc::num_cu();        // agg_fix has two entries for every wave of the full grid
-  mlp_resident_kernel<HT, OT, NMM, NADD, RESREG, AGG, SAVE>
+  mlp_resident_kernel<HT, OT, NMM, NADD, RESREG, AGG, SAVE, FULL>
       <<<dim3((unsigned)grid), dim3(RNT), smem, stream>>>(d, (int)num_wtiles, total_chunks);
   return gnc::check_launch("mlp_resident_kernel");
 }
@@ -519,6 +522,11 @@ int gnc_mlp::launch_resident(const gnc_mlp_desc_t& d, int T, bool narrow_out, hi
   const bool resreg = d.residual && d.residual == lm.ptr && !lm.index && lm.ld == d.ld_residual && lm.width == od;
 
   if (narrow_out && (resreg || nadd || nmm != 1)) return GNC_OK;  // out width <= 32 (the decoder): plain shapes only
+  // every width exactly 64, three Linear layers, LayerNorm, whole 16-B output rows: the FULL instances (c3's edge processor)
+  static const bool no_full = getenv("GNC_MLP_NO_FULL64") != nullptr;  // A/B switch
+  bool full64 = !no_full && L == 3 && od == KC && d.ln_gamma && d.ld_out % 4 == 0 && al16(d.out);
+  for (int s = 0; s < d.num_segments; ++s) full64 = full64 && d.seg[s].width == KC;
+  for (int l = 0; l < L; ++l) full64 = full64 && d.out_dim[l] == KC && (l == 0 || d.in_dim[l] == KC);
   if (d.save_act[0]) {
     // training forward: SAVE instances exist for the shapes whose K8 kernel reads the saved tensors (the fused data +
     // weight-gradient kernel: widths 33..64, ONE row-ordered MATMUL segment, 0 or 2 gathered ADD segments)
@@ -527,7 +535,8 @@ int gnc_mlp::launch_resident(const gnc_mlp_desc_t& d, int T, bool narrow_out, hi
     if (nadd == 2 && !resreg) return GNC_OK;
     *launched = true;
     if (probe_only) return GNC_OK;
-    if (d.agg_out) return launch<2, 2, 1, 2, true, true, true>(d, total_chunks, smem, stream);
+    if (d.agg_out) return full64 ? launch<2, 2, 1, 2, true, true, true, true>(d, total_chunks, smem, stream)
+                                 : launch<2, 2, 1, 2, true, true, true>(d, total_chunks, smem, stream);
     if (nadd == 2) return launch<2, 2, 1, 2, true, false, true>(d, total_chunks, smem, stream);
     return resreg ? launch<2, 2, 1, 0, true, false, true>(d, total_chunks, smem, stream)
                   : launch<2, 2, 1, 0, false, false, true>(d, total_chunks, smem, stream);
@@ -536,6 +545,7 @@ int gnc_mlp::launch_resident(const gnc_mlp_desc_t& d, int T, bool narrow_out, hi
     if (!(nadd == 2 && nmm == 1 && resreg && !narrow_out && d.agg_index && d.agg_fix && d.ld_agg >= od)) return GNC_OK;
     *launched = true;
     if (probe_only) return GNC_OK;
+    if (T == 2 && full64) return launch<2, 2, 1, 2, true, true, false, true>(d, total_chunks, smem, stream);
     return T == 2 ? launch<2, 2, 1, 2, true, true>(d, total_chunks, smem, stream)
                   : launch<1, 1, 1, 2, true, true>(d, total_chunks, smem, stream);
   }
