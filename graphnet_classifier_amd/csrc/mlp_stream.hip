@@ -125,6 +125,13 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_stream_kernel(const gnc_mlp_de
     agg_t0 = gwave * q + (gwave < rem ? gwave : rem);
     agg_cnt = q + (gwave < rem ? 1 : 0);
     iters = q + ((int)blockIdx.x * WAVES < rem ? 1 : 0);
+    if (iters == 0) {  // workgroup-uniform: nothing to do (small batches on the full grid) but to report "no destination"
+      if (lane == 0) {
+        d.agg_fix[2 * gwave] = -1;
+        d.agg_fix[2 * gwave + 1] = -1;
+      }
+      return;
+    }
   } else {
     iters = (num_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   }
@@ -481,7 +488,7 @@ int launch(const gnc_mlp_desc_t& d, const StreamPlan& pl, hipStream_t stream) {
   }
   const int64_t num_tiles = gnc::ceil_div(d.rows, (int64_t)WAVES * RPW);
   int64_t grid = num_tiles < gnc::num_cu() ? num_tiles : gnc::num_cu();  // one persistent workgroup per CU
-  if constexpr (AGG) grid = gnc::num_cu();  // agg_fix has two entries for every wave of the full grid (8 waves per workgroup)
+  if constexpr (AGG) grid = gnc::num_cu() * 8 / WAVES;  // agg_fix has two entries for each of the 8 x num_cu waves of the full grid
   mlp_stream_kernel<HT, OT, WAVES, DBUF, ADD2, AGG, SAVE><<<dim3((unsigned)grid), dim3(WAVES * 64), smem, stream>>>(d, pl, (int)num_tiles);
   return gnc::check_launch("mlp_stream_kernel");
 }
@@ -544,6 +551,9 @@ int gnc_mlp::launch_stream(const gnc_mlp_desc_t& d, int T, bool narrow_out, hipS
       return GNC_OK;
     *launched = true;
     if (probe_only) return GNC_OK;
+    // small batches (the reference's one-graph-per-call regime): 2-wave workgroups as below, four times as many of them
+    if (d.rows <= (int64_t)2 * RPW * gnc::num_cu())
+      return save ? launch<4, 4, 2, true, false, true, true>(d, pl, stream) : launch<4, 4, 2, true, false, true>(d, pl, stream);
     return save ? launch<4, 4, 8, true, false, true, true>(d, pl, stream) : launch<4, 4, 8, true, false, true>(d, pl, stream);
   }
   *launched = true;
