@@ -144,7 +144,8 @@ __device__ __forceinline__ void fmma_transposed_from_regs(f32x16 (&dst)[2], cons
 }
 
 // acc[a][c] += sum over the tile's 32 rows of tm[row][32a + .] (x) tk[row][32c + .]; csum[a] += column sums of tm
-__device__ __forceinline__ void xty_tile(f32x16 (&acc)[2][2], float (&csum)[2], const float* tm, const float* tk, int i, int h) {
+__device__ __forceinline__ void xty_tile(f32x16 (&acc)[2][2], float (&csum)[2], const float* tm, const float* tk, int i, int h,
+                                         bool both = true) {  // both (wave-uniform) = false: tk holds at most 32 columns
   // software-pipelined by one step: the four column reads of step s + 1 are in flight under the four MFMAs of step s
   float av[2], bv[2];
 #pragma unroll
@@ -162,9 +163,11 @@ __device__ __forceinline__ void xty_tile(f32x16 (&acc)[2][2], float (&csum)[2], 
 #pragma unroll
     for (int a = 0; a < 2; ++a) csum[a] += av[a];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 2; ++a) mfma_agpr(acc[a][0], av[a], bv[0]);
+    if (both) {  // the encoders' 3-column inputs: half the MFMAs of their first Linear's weight gradient
 #pragma unroll
-      for (int c = 0; c < 2; ++c) mfma_agpr(acc[a][c], av[a], bv[c]);
+      for (int a = 0; a < 2; ++a) mfma_agpr(acc[a][1], av[a], bv[1]);
+    }
 #pragma unroll
     for (int a = 0; a < 2; ++a) av[a] = na[a];
 #pragma unroll
@@ -469,7 +472,7 @@ __global__ __launch_bounds__(FNT) void mlp_backward_fused_kernel(const gnc_mlp_d
     gather_rows_of(pa, pb, nrow0);
     // ---------------------------------------------------------------- layer 0: dW0 += dz0^T e, dz0 out, dx
     acc_to_tile(tb, g);
-    xty_tile(dW0, cs0, tb, te, i, h);
+    xty_tile(dW0, cs0, tb, te, i, h, NADD != 0 || s0.width > 32);
     to_tile(te, pe, s0.width);  // this tile's e rows are done with: the next tile's (requested two layers ago) move in
     sum_gathered();  // the next tile's gathered rows have landed under dW0: one register set instead of two from here on
     f32x4 gres[NP];  // requested as late as the dx product still covers (L2 / MALL hits): 32 registers less under dW0
