@@ -4,8 +4,9 @@
 // through models/MLP.py:45-47 and the concat / residual around it (models/GNN.py:58-62, :100-102).
 //
 // mlp_backward_data_kernel  (one launch per MLP call, same tiling as the weights-resident forward):
-//   recomputes the forward of its 32-row tile on the fp32 MFMA path (nothing was saved by the forward
-//   but its inputs), then walks the chain backwards with the SAME resident weight chunks read
+//   recomputes the forward of its 32-row tile on the fp32 MFMA path (this kernel serves the shapes whose forward
+//   saves nothing: two MATMUL segments, the node processors; the streamed and the fused kernels read the training
+//   forward's saved post-activations instead, gnc_mlp_bwd_desc_t.act_given), then walks the chain backwards with the SAME resident weight chunks read
 //   transposed (ds_read_b32 down a column):
 //        g            -> LayerNorm backward -> dy            (and per-wave partial sums of d gamma, d beta)
 //        da_l = W_{l+1}^T dz_{l+1},  dz_l = da_l * (a_l > 0)   for l = L-2 .. 0   (ReLU masks: 1 bit per value)

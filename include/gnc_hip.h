@@ -220,8 +220,11 @@ int gnc_agg_fixup_f32(const float* src, int64_t ld_src, const int32_t* rowptr, c
  * models/MLP.py:45-47 and the concat/residual around it.  Two kernels:
  *
  * gnc_mlp_backward_f32: given the forward description `fwd` (its `out` field is ignored) and
- *   grad_out = dL/d(out) [rows, out_dim], recomputes the forward per 32-row tile and writes
- *     act[l]  [rows, out_dim[l]]  post-activation output of Linear l, l < num_linear-1 (input of Linear l+1)
+ *   grad_out = dL/d(out) [rows, out_dim], recomputes the forward per 32-row tile - or, with act_given (ABI 16), reads the
+ *   post-activations the training forward saved (gnc_mlp_desc_t.save_act) and recomputes only the last Linear for the
+ *   LayerNorm statistics - and writes
+ *     act[l]  [rows, out_dim[l]]  post-activation output of Linear l, l < num_linear-1 (input of Linear l+1); an INPUT
+ *                                 with act_given
  *     dz[l]   [rows, out_dim[l]]  dL/d(pre-activation of Linear l); dz[num_linear-1] is dL/d(pre-LayerNorm y)
  *     dx      [rows, in_dim[0]]   dL/d(MATMUL part of the input concat), column order = wcol; NULL to skip
  *     yhat    [rows, out_dim]     normalised pre-affine output of the LayerNorm (required with LayerNorm):
