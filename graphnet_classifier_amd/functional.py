@@ -90,20 +90,25 @@ class _FusedMLP(torch.autograd.Function):
         ln = (rest.pop(0), rest.pop(0), meta.ln_eps) if meta.has_ln else None
         residual = rest.pop(0) if meta.has_residual else None
         # training forward: the kernel also leaves the hidden layers' post-activations (what autograd would keep) for K8
-        ctx.acts = [] if (meta.training and any(ctx.needs_input_grad) and HIP_BACKWARD) else None
+        acts = [] if (meta.training and any(ctx.needs_input_grad) and HIP_BACKWARD) else None
         out = native.mlp_forward(list(zip(tables, meta.indices)), list(weights), list(biases), ln=ln,
                                  activation=meta.activation, act_param=meta.act_param, residual=residual, rows=meta.rows,
-                                 save_act=ctx.acts)
+                                 save_act=acts)
         ctx.meta = meta
-        ctx.save_for_backward(*args)
+        # the saved post-activations go through save_for_backward like the inputs: autograd then frees them as soon as this
+        # node's backward has run (held as plain attributes they lived until the whole graph died: +30 GB at c5)
+        ctx.n_acts = len(acts) if acts else 0
+        ctx.save_for_backward(*args, *(acts or []))
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        meta, args = ctx.meta, ctx.saved_tensors
+        meta, saved = ctx.meta, ctx.saved_tensors
+        args = saved[:len(saved) - ctx.n_acts]
+        acts = list(saved[len(saved) - ctx.n_acts:]) if ctx.n_acts else None
         s, l = len(meta.indices), meta.num_linear
         need = ctx.needs_input_grad[1:]
-        hip = _fused_mlp_backward_hip(meta, args, need, grad_out, ctx.acts) if HIP_BACKWARD else None
+        hip = _fused_mlp_backward_hip(meta, args, need, grad_out, acts) if HIP_BACKWARD else None
         if hip is not None:
             return (None,) + hip
         leaves = [a.detach().requires_grad_(bool(n)) for a, n in zip(args, need)]
@@ -221,17 +226,20 @@ class _EdgeProcessorWSplit(torch.autograd.Function):
         ps = native.mlp_forward([(x, None)], [w0[:, :dn]], [None])           # [N, H] = x Ws^T
         pd = native.mlp_forward([(x, None)], [w0[:, dn:2 * dn]], [None])     # [N, H] = x Wd^T
         training = len(meta) > 8 and meta[8] and any(ctx.needs_input_grad) and HIP_BACKWARD
-        ctx.acts = [] if training else None   # the hidden layers' post-activations, kept for K8 where the kernel can
-        ctx.proj = (ps, pd) if training else None  # the backward's gathered inputs again: [N, H] each, kept
+        acts = [] if training else None   # the hidden layers' post-activations, kept for K8 where the kernel can
         out = native.mlp_forward([(ps, src), (pd, dst), (e, None)], [w0[:, 2 * dn:]] + weights[1:], biases, ln=ln,
                                  activation=activation, act_param=act_param, residual=e, rows=e.size(0),
                                  modes=[native.SEG_ADD, native.SEG_ADD, native.SEG_MATMUL],
                                  aggregate=(topo.dst_sorted, topo.rowptr, topo.num_nodes) if with_agg else None,
-                                 save_act=ctx.acts)
+                                 save_act=acts)
+        # kept for the backward through save_for_backward (freed when this node's backward has run): the projections - its
+        # gathered inputs again, [N, H] each - and the post-activations
+        extra = ([ps, pd] + acts) if training else []
+        ctx.n_extra = len(extra)
         ctx.meta = meta[:7]
         ctx.with_agg = with_agg
         ctx.set_materialize_grads(False)  # an unused output (the last block's e') arrives as None, not as zeros
-        ctx.save_for_backward(x, e, *params)
+        ctx.save_for_backward(x, e, *params, *extra)
         if not with_agg:
             return out
         out, agg = out
@@ -256,7 +264,9 @@ class _EdgeProcessorWSplit(torch.autograd.Function):
             grad_out = native.gather_rows_add(grad_agg.contiguous(), dst, grad_out.contiguous())
         elif grad_agg is not None:
             grad_out = native.gather_rows(grad_agg.contiguous(), dst)
-        leaves = [a.detach().requires_grad_(bool(n)) for a, n in zip(ctx.saved_tensors, need)]
+        saved = ctx.saved_tensors
+        saved = saved[:len(saved) - getattr(ctx, "n_extra", 0)]
+        leaves = [a.detach().requires_grad_(bool(n)) for a, n in zip(saved, need)]
         x, e, params = leaves[0], leaves[1], leaves[2:]
         act = _torch_activation(activation, act_param)
         with torch.enable_grad():
@@ -280,8 +290,12 @@ def _edge_wsplit_backward_hip(ctx, grad_out, grad_agg=None):
     src, dst, num_linear, activation, act_param, ln_eps, has_ln = ctx.meta
     topo = ctx.topo
     need = ctx.needs_input_grad[2:]
-    x, e = ctx.saved_tensors[0], ctx.saved_tensors[1]
-    params = list(ctx.saved_tensors[2:])
+    saved = ctx.saved_tensors
+    n_extra = getattr(ctx, "n_extra", 0)
+    extra = list(saved[len(saved) - n_extra:]) if n_extra else []
+    saved = saved[:len(saved) - n_extra]
+    x, e = saved[0], saved[1]
+    params = list(saved[2:])
     weights, biases = params[:num_linear], params[num_linear:2 * num_linear]
     ln = (params[2 * num_linear], params[2 * num_linear + 1], ln_eps) if has_ln else None
     if topo is None or activation != "ReLU" or not (grad_out if grad_out is not None else grad_agg).is_cuda:
@@ -291,8 +305,8 @@ def _edge_wsplit_backward_hip(ctx, grad_out, grad_agg=None):
     h = w0.size(0)
     ws_, wd_, we_ = w0[:, :dn], w0[:, dn:2 * dn], w0[:, 2 * dn:]
     # the forward's projections are needed again as the gathered additive inputs (kept by the training forward)
-    if getattr(ctx, "proj", None) is not None:
-        ps, pd = ctx.proj
+    if extra:
+        ps, pd = extra[0], extra[1]
     else:
         ps = native.mlp_forward([(x, None)], [ws_], [None])
         pd = native.mlp_forward([(x, None)], [wd_], [None])
@@ -304,7 +318,7 @@ def _edge_wsplit_backward_hip(ctx, grad_out, grad_agg=None):
     r = native.mlp_backward(segments, wl, biases, ln, grad_out.contiguous() if grad_out is not None else None, rows=e.size(0),
                             modes=modes, need_dx=bool(need[1]), residual=e,
                             grad_gather=(grad_agg.contiguous(), dst) if grad_agg is not None else None,
-                            saved_act=getattr(ctx, "acts", None))
+                            saved_act=extra[2:] or None)
     grad_out = r["grad_out"]  # effective row-ordered gradient (None when the launch gathered part of it itself)
     dz0 = r["dz"][0]
     grads = [None] * (2 + len(params))
