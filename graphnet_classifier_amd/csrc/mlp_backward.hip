@@ -30,7 +30,9 @@ constexpr int BWAVES = 8;
 constexpr int BNT = BWAVES * 64;
 
 // HT = tiles of the hidden AND output width (both <= 64).  NMM / NADD as in mlp_resident.hip.
-template <int HT, int NMM, int NADD>
+// SAVED: b.act[] are the training forward's saved post-activations (inputs): no forward recompute but the last Linear's
+// (LayerNorm statistics), nothing emitted for them
+template <int HT, int NMM, int NADD, bool SAVED = false>
 __global__ __launch_bounds__(BNT) void mlp_backward_data_kernel(const gnc_mlp_desc_t d, const BwdArgs b,
                                                                 const int num_wtiles, const int total_chunks) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -131,10 +133,27 @@ __global__ __launch_bounds__(BNT) void mlp_backward_data_kernel(const gnc_mlp_de
   for (int wt = (int)blockIdx.x * BWAVES + wave; wt < num_wtiles; wt += total_waves) {
     const int row0 = wt * RPW;
 
-    // ------------------------------------------------------------------ forward recompute
     f32x16 hid[HT];
-    init_bias<HT>(hid, pbuf, h);
     f32x4 gpre[NP];  // grad_out rows of this tile: requested early, consumed after the forward recompute
+    unsigned mask[GNC_MAX_LINEAR - 1];
+    if constexpr (SAVED) {
+      // the saved tiles give the ReLU masks; the last one stays in registers for the LayerNorm recompute
+      f32x4 pre[NP];
+      load_rows_seq(pre, b.act[0], d.out_dim[0], row0);
+#pragma unroll
+      for (int l = 0; l < GNC_MAX_LINEAR - 1; ++l) {
+        if (l < L - 1) {
+          stage(pre, d.out_dim[l]);
+          if (l + 1 < L - 1) load_rows_seq(pre, b.act[l + 1 < GNC_MAX_LINEAR ? l + 1 : 0], d.out_dim[l + 1 < GNC_MAX_LINEAR ? l + 1 : 0], row0);
+          else load_rows_seq(gpre, b.grad_out, b.ld_grad_out, row0);
+          tile_from_lds<HT>(hid, abuf, i, h);
+          compiler_lds_barrier();
+          mask[l] = relu_tiles_mask<HT>(hid);
+        }
+      }
+    } else {
+    // ------------------------------------------------------------------ forward recompute
+    init_bias<HT>(hid, pbuf, h);
     {
       f32x4 pre[NP], pre2[NP], pre3[NP];
       load_seg(pre, sv[0], wt);
@@ -160,7 +179,6 @@ __global__ __launch_bounds__(BNT) void mlp_backward_data_kernel(const gnc_mlp_de
         add_tile_from_lds<HT>(hid, abuf, i, h);
       }
     }
-    unsigned mask[GNC_MAX_LINEAR - 1];
     mask[0] = relu_tiles_mask<HT>(hid);
     emit(hid, b.act[0], d.out_dim[0], d.out_dim[0], row0);
 #pragma unroll
@@ -175,6 +193,7 @@ __global__ __launch_bounds__(BNT) void mlp_backward_data_kernel(const gnc_mlp_de
         emit(hid, b.act[l], d.out_dim[l], d.out_dim[l], row0);
       }
     }
+    }  // forward recompute
 
     // ------------------------------------------------------------------ grad of the pre-LayerNorm output
     f32x16 g[HT];
@@ -1019,18 +1038,18 @@ int bwd_shape(const gnc_mlp_desc_t& d, int* nmm_out, int* nadd_out, int* T_out) 
   return 1;
 }
 
-template <int HT, int NMM, int NADD>
+template <int HT, int NMM, int NADD, bool SAVED = false>
 int launch_bwd(const gnc_mlp_desc_t& d, const BwdArgs& b, int total_chunks, size_t smem, int grid, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    int rc = gnc::check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_backward_data_kernel<HT, NMM, NADD>),
+    int rc = gnc::check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_backward_data_kernel<HT, NMM, NADD, SAVED>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
                             "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc) return rc;
     attr_set = true;
   }
   const int64_t num_wtiles = gnc::ceil_div(d.rows, RPW);
-  mlp_backward_data_kernel<HT, NMM, NADD>
+  mlp_backward_data_kernel<HT, NMM, NADD, SAVED>
       <<<dim3((unsigned)grid), dim3(BNT), smem, stream>>>(d, b, (int)num_wtiles, total_chunks);
   return gnc::check_launch("mlp_backward_data_kernel");
 }
@@ -1275,6 +1294,7 @@ extern "C" int gnc_mlp_backward_f32(const gnc_mlp_bwd_desc_t* bd, void* stream_)
   if (smem > 160 * 1024) { gnc::set_error("gnc_mlp_backward_f32: weights do not fit in LDS"); return GNC_ERR_UNSUPPORTED; }
   hipStream_t stream = (hipStream_t)stream_;
 #define GNC_BWD(HT_, NMM_, NADD_) return launch_bwd<HT_, NMM_, NADD_>(d, b, total_chunks, smem, grid, stream)
+  if (saved) return launch_bwd<2, 2, 0, true>(d, b, total_chunks, smem, grid, stream);  // (the support query admits only this shape)
   if (T == 2) {
     if (nadd == 2) GNC_BWD(2, 1, 2);
     if (nmm == 1) GNC_BWD(2, 1, 0);
@@ -1299,7 +1319,9 @@ extern "C" int gnc_mlp_backward_saved_act_honoured(const gnc_mlp_bwd_desc_t* bd)
   // split path: the streaming kernels read them (and gnc_xty_f32 after them); the weights-resident data kernel recomputes
   int nmm, nadd, T;
   BwdPlan pl;
-  if (d.num_linear < 2 || bwd_shape(d, &nmm, &nadd, &T)) return 0;
+  if (d.num_linear < 2) return 0;
+  // weights-resident data kernel: a SAVED instance exists for the node processors' shape (widths 33..64, two MATMUL segments)
+  if (bwd_shape(d, &nmm, &nadd, &T)) return (T == 2 && nmm == 2 && nadd == 0) ? 1 : 0;
   // SAVED instances exist for the 65..128 class of the 32-row kernel and for the 16-row kernel (129..256)
   if (bwd_stream_plan(d, bd->dx != nullptr, &pl, &T, true)) return T == 4 ? 1 : 0;
   return use_stream16(d, bd->dx != nullptr) ? 1 : 0;

@@ -530,11 +530,15 @@ int gnc_mlp::launch_resident(const gnc_mlp_desc_t& d, int T, bool narrow_out, hi
   if (d.save_act[0]) {
     // training forward: SAVE instances exist for the shapes whose K8 kernel reads the saved tensors (the fused data +
     // weight-gradient kernel: widths 33..64, ONE row-ordered MATMUL segment, 0 or 2 gathered ADD segments)
-    if (T != 2 || narrow_out || nmm != 1 || L < 2) return GNC_OK;
+    if (T != 2 || narrow_out || nmm > 2 || L < 2) return GNC_OK;
+    if (nmm == 2 && (nadd != 0 || d.agg_out)) return GNC_OK;  // two MATMUL segments: the node processors (split K8 path)
     if (d.agg_out && !(nadd == 2 && resreg && d.agg_index && d.agg_fix && d.ld_agg >= od)) return GNC_OK;
     if (nadd == 2 && !resreg) return GNC_OK;
     *launched = true;
     if (probe_only) return GNC_OK;
+    if (nmm == 2)
+      return resreg ? launch<2, 2, 2, 0, true, false, true>(d, total_chunks, smem, stream)
+                    : launch<2, 2, 2, 0, false, false, true>(d, total_chunks, smem, stream);
     if (d.agg_out) return full64 ? launch<2, 2, 1, 2, true, true, true, true>(d, total_chunks, smem, stream)
                                  : launch<2, 2, 1, 2, true, true, true>(d, total_chunks, smem, stream);
     if (nadd == 2) return launch<2, 2, 1, 2, true, false, true>(d, total_chunks, smem, stream);

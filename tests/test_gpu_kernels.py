@@ -565,7 +565,8 @@ def test_mlp_backward_gathered_output_gradient(native, d, e, with_rows):
 @pytest.mark.parametrize("d,e,nadd,gg", [(64, 2111, 2, 0), (64, 2111, 2, 1), (64, 2111, 2, 2), (48, 1000, 2, 1), (40, 333, 0, 0),
                                          (64, 32 * 1024 * 3 + 7, 2, 1), (64, 32 * 1024 * 2 + 31, 0, 0), (64, 5, 2, 2),
                                          (128, 2111, 2, 0), (128, 70001, 2, 1), (100, 999, 0, 0), (96, 1500, 2, 2),
-                                         (256, 2111, 2, 0), (256, 40001, 2, 1), (200, 999, 0, 0), (192, 700, 2, 2), (132, 300, 2, 0)])
+                                         (256, 2111, 2, 0), (256, 40001, 2, 1), (200, 999, 0, 0), (192, 700, 2, 2), (132, 300, 2, 0),
+                                         (64, 4099, -2, 0), (48, 777, -2, 0)])
 def test_mlp_backward_saved_activations(native, d, e, nadd, gg):
     """ABI 16: the training forward keeps the hidden layers' post-activations (`save_act`, written by the weights-resident
     kernel straight from its accumulators) and the fused K8 kernel reads them (`act_given`) instead of recomputing the first
@@ -582,7 +583,11 @@ def test_mlp_backward_saved_activations(native, d, e, nadd, gg):
     ln = (sd["m.model.5.weight"].to(DEV), sd["m.model.5.bias"].to(DEV), 1e-5)
     src = torch.from_numpy(rng.integers(0, n, size=e).astype(np.int32)).to(DEV)
     dst = torch.from_numpy(np.sort(rng.integers(0, n, size=e)).astype(np.int32)).to(DEV)
-    if nadd:
+    if nadd == -2:  # the node processor's shape: two row-ordered MATMUL segments [x | agg], residual x (split K8 path)
+        agg_in = t(rng.standard_normal((e, d)))
+        ws[0] = t(rng.uniform(-1, 1, (d, 2 * d)) / np.sqrt(2 * d))
+        segs, modes, nadd = [(ea, None), (agg_in, None)], None, 0
+    elif nadd:
         ps, pd_ = t(rng.standard_normal((n, d))), t(rng.standard_normal((n, d)))
         segs, modes = [(ps, src), (pd_, dst), (ea, None)], [native.SEG_ADD, native.SEG_ADD, native.SEG_MATMUL]
     else:
@@ -592,7 +597,7 @@ def test_mlp_backward_saved_activations(native, d, e, nadd, gg):
     assert len(acts) == 2 and acts[0].shape == (e, d)
     plain = native.mlp_forward(segs, ws, bs, ln=ln, residual=ea, rows=e, modes=modes)
     assert torch.equal(out, plain)  # saving changes nothing about the output
-    z0 = ea.cpu() @ ws[0].cpu().t() + bs[0].cpu()
+    z0 = torch.cat([sg[0].cpu() for sg in segs if sg[1] is None], dim=1) @ ws[0].cpu().t() + bs[0].cpu()
     if nadd:
         z0 = z0 + ps.cpu()[src.cpu().long()] + pd_.cpu()[dst.cpu().long()]
     a0 = torch.relu(z0)
