@@ -353,6 +353,16 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_backward_stream_kernel(const g
     const int ldw = ldw_of(d, layer);
     const int nrows = d.out_dim[layer];
     const int klimit = pl.wc[q].klimit;
+    if (pl.wc[q].kbase + KC <= klimit && (int64_t)nrows * ldw * 4 <= 0xffffffffll) {
+      // full 64-column chunk (the plan guarantees aligned weights): a window over the matrix, rows >= nrows read as 0
+      // through the bounds check - no masks, one 32-bit add per load (as in mlp_stream.hip; the masked form below cost
+      // ~10 vector instructions per piece, 40 per chunk and thread)
+      const __amdgpu_buffer_rsrc_t w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, nrows * ldw * 4, 0x00020000);
+      const uint32_t off0 = (uint32_t)(wr0 * ldw + pl.wc[q].kbase + wc4 * 4) * 4u;
+#pragma unroll
+      for (int p = 0; p < NW; ++p) wr[p] = window_load(w, off0 + (uint32_t)(p * RPP * 4) * (uint32_t)ldw);
+      return;
+    }
     const int col = pl.wc[q].kbase + wc4 * 4;
     const int colc = col < klimit ? col : pl.wc[q].kbase;
 #pragma unroll
