@@ -483,9 +483,11 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_backward_stream_kernel(const g
       for (int cc = 0; cc < NCH; ++cc) {
         if (cc * KC < width) {
           f32x4 pre[NP];
-          int r = row0 + (fresh_lane() & 31);
-          r = r < rows ? r : rows - 1;
-          load_rows(pre, base, ld, cc * KC, r);
+          {  // row-ordered: one window per tile, no per-piece address arithmetic; rows past the end read 0
+            const int fl = fresh_lane();
+            const int col = cc * KC + (fl & 15) * 4;
+            load_tile_rows(pre, base, ld, row0, rows, (uint32_t)((fl >> 4) * ld + (col < ld ? col : 0)) * 4u);
+          }
           stage(pre, cc * KC, width);
 #pragma unroll
           for (int tt = 0; tt < 2; ++tt)
@@ -600,9 +602,11 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_backward_stream_kernel(const g
     for (int cc = 0; cc < NCH; ++cc) {
       if (cc * KC < out_dim) {
         f32x4 pre[NP];
-        int r = row0 + (fresh_lane() & 31);
-        r = r < rows ? r : rows - 1;
-        load_rows(pre, b.grad_out, b.ld_grad_out, cc * KC, r);
+        {  // row-ordered: one window per tile (rows past the end read 0: their gradients are never stored)
+          const int fl = fresh_lane();
+          const int col = cc * KC + (fl & 15) * 4;
+          load_tile_rows(pre, b.grad_out, b.ld_grad_out, row0, rows, (uint32_t)((fl >> 4) * b.ld_grad_out + (col < b.ld_grad_out ? col : 0)) * 4u);
+        }
         stage(pre, cc * KC, out_dim);
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt)
