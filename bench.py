@@ -258,7 +258,9 @@ def main():
         torch.cuda.synchronize()
         try:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # thread_local: what OTHER threads do meanwhile (the process group's watchdog polls its events) must not
+            # invalidate this capture; only this thread's own unsafe calls may
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 graph_out = step()
             graph.replay()
             torch.cuda.synchronize()
