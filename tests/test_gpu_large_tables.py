@@ -176,6 +176,39 @@ def test_mlp_backward_row_tables_beyond_4gib(native, width):
         assert torch.equal(a[lo:], b)
 
 
+@pytest.mark.parametrize("width", [64, 128, 256])
+def test_saved_activations_beyond_4gib(native, width):
+    """ABI 16 on tables larger than 4 GiB: the training forward's saved post-activations ([rows, H] each: written through a
+    window per tile beyond the offset) equal the tensors the recomputing K8 kernel emits, and the K8 kernel that READS them
+    gives the recomputing kernel's gradients - every row beyond the 4 GiB offset included."""
+    rng = np.random.default_rng(width + 11)
+    rows = _rows_for(width, 33_333)
+    sd = _mlp_sd(rng, width, width, width, 2, True)
+    ws, bs, ln = _dev_params(sd)
+    gen = torch.Generator(device=DEV).manual_seed(width + 1)
+    x = torch.randn(rows, width, device=DEV, generator=gen)
+    g = torch.randn(rows, width, device=DEV, generator=gen)
+    segs = [(x, None)]
+    acts = []
+    native.mlp_forward(segs, ws, bs, ln=ln, rows=rows, save_act=acts)
+    if not acts:
+        pytest.skip(f"no saving forward kernel at width {width}")
+    ref = native.mlp_backward(segs, ws, bs, ln, g, rows=rows, need_dx=True, fused=False)
+    assert not ref["saved_act_used"]
+    for a, b in zip(acts, ref["act"]):  # forward-saved == recomputed-and-emitted, over the whole table
+        assert float((a - b).abs().max()) < 1e-5
+    r = native.mlp_backward(segs, ws, bs, ln, g, rows=rows, need_dx=True, saved_act=acts)
+    assert r["saved_act_used"]
+    edge = FOUR_GIB // (4 * width)
+    # rows whose pre-activation lies within rounding of 0 may take the other side of the ReLU in the two forms: compare
+    # row-wise and admit a handful of them in these 8-17 million rows
+    bad = (r["dx"] - ref["dx"]).abs().amax(dim=1) >= 1e-5
+    assert int(bad.sum()) <= 8, int(bad.sum())
+    assert int((~bad[edge:]).sum()) >= rows - edge - 8  # ... and the rows beyond the offset are among the good ones
+    del ref, r
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("width", [128, 256])
 def test_weight_gradient_product_beyond_4gib(native, width):
     """xty (dW = dz^T a, db = colsum(dz)) with both operands larger than 4 GiB: against a float64 product, and the rows
