@@ -209,6 +209,38 @@ def test_saved_activations_beyond_4gib(native, width):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("with_rows", [True, False])
+def test_gathered_output_gradient_beyond_4gib(native, with_rows):
+    """ABI 16 `grad_gather` in the fused K8 kernel (W-split shape, width 64) with row tables larger than 4 GiB: the launch
+    that gathers the aggregation's gradient itself equals the launch on the materialised gradient - bit for bit for dz_0 and
+    the weight gradients, to rounding for dx - including the rows beyond the offset (the summed-rows scratch tensor of the
+    rows + gathered form is itself larger than 4 GiB)."""
+    width, n = 64, 100_003
+    rng = np.random.default_rng(5 + with_rows)
+    rows = _rows_for(width, 12_345)
+    sd = _mlp_sd(rng, width, width, width, 2, True)
+    ws, bs, ln = _dev_params(sd)
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    ea = torch.randn(rows, width, device=DEV, generator=gen)
+    ps, pd_ = torch.randn(n, width, device=DEV, generator=gen), torch.randn(n, width, device=DEV, generator=gen)
+    gagg = torch.randn(n, width, device=DEV, generator=gen)
+    src = torch.randint(0, n, (rows,), device=DEV, generator=gen, dtype=torch.int32)
+    dst = torch.sort(torch.randint(0, n, (rows,), device=DEV, generator=gen, dtype=torch.int32))[0]
+    gout = torch.randn(rows, width, device=DEV, generator=gen) if with_rows else None
+    segs = [(ps, src), (pd_, dst), (ea, None)]
+    modes = [native.SEG_ADD, native.SEG_ADD, native.SEG_MATMUL]
+    g_eff = native.gather_rows(gagg, dst) if gout is None else native.gather_rows_add(gagg, dst, gout)
+    ref = native.mlp_backward(segs, ws, bs, ln, g_eff, rows=rows, modes=modes, need_dx=True, residual=ea)
+    del g_eff
+    r = native.mlp_backward(segs, ws, bs, ln, gout, rows=rows, modes=modes, need_dx=True, residual=ea, grad_gather=(gagg, dst))
+    torch.cuda.synchronize()
+    assert r["grad_out"] is None and "dw" in r  # gathered inside the fused launch
+    assert torch.equal(r["dz"][0], ref["dz"][0])
+    assert float((r["dx"] - ref["dx"]).abs().max()) < 2e-6
+    for a, b in zip(r["dw"] + r["db"] + list(r["ln_sums"]), ref["dw"] + ref["db"] + list(ref["ln_sums"])):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("width", [128, 256])
 def test_weight_gradient_product_beyond_4gib(native, width):
     """xty (dW = dz^T a, db = colsum(dz)) with both operands larger than 4 GiB: against a float64 product, and the rows
