@@ -125,6 +125,10 @@ def main():
                          "of enqueueing its ~40 launches from Python every step.  auto = on for N > 1 (a 1/8 shard of c3 is 1.3 ms "
                          "of kernels behind 1.5 ms of host enqueue: tools/host_profile.py), off at N = 1 (GPU-bound either way, and "
                          "the per-launch HIP events of the roofline objects then live inside the timed region)")
+    ap.add_argument("--train-graph", default="auto", choices=["auto", "on", "off"],
+                    help="training step: replay forward + CE + backward + gradient pack from ONE hipGraph (train.CapturedTrainStep) "
+                         "and issue the all-reduce and the fused Adam launch directly after it (world > 1; at world 1 the Adam "
+                         "launch is inside the graph).  auto = on for N > 1 (a 1/8 shard's training step is launch-bound)")
     ap.add_argument("--mode", default="forward", choices=["forward", "train"],
                     help="train: the timed step is forward + cross-entropy + backward (HIP K8 kernels) + one flat gradient "
                          "all-reduce (RCCL, world > 1) + fused Adam, graphs batched block-diagonally")
@@ -190,7 +194,36 @@ def main():
         opt = FusedAdam(flat, lr=1e-3)                            # utils/train_model.py:9
         crit = torch.nn.CrossEntropyLoss(reduction="sum")         # :10, mean taken over the GLOBAL batch below
         gptr = None if equal else batch.graph_ptr.to(dev)
-        ar = {"events": []}
+        ar = {"events": [], "launch": "eager launches from Python"}
+
+        def batched(mod, xx, pp, ee):
+            clear_topology_cache()  # the CSR build belongs to the step (captured with it)
+            return mod.forward_batched(xx, pp, ee, batch.num_graphs) if equal else mod.forward_batched(xx, pp, ee, graph_ptr=gptr)
+
+        if a.train_graph == "on" or (a.train_graph == "auto" and world > 1):
+            from graphnet_classifier_amd.train import CapturedTrainStep
+            try:
+                loss_sum = torch.zeros((), dtype=torch.float64, device=dev)
+                # thread_local: the process group's watchdog thread polls its events meanwhile
+                cap = CapturedTrainStep(cmodel, opt, crit, (x, pos, ei), labels, loss_sum, forward=batched,
+                                        loss_scale=1.0 / global_graphs, capture_error_mode="thread_local")
+
+                def tstep_replay():
+                    cap.graph.replay()
+                    if cap.collective_outside:
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        flat.reducer.allreduce()   # ONE all-reduce of the packed flat buffer (RCCL)
+                        e1.record()
+                        ar["events"].append((e0, e1))
+                        opt.step(reduce=False)     # one fused Adam launch over the flat buffers
+                    return None
+                ar["launch"] = ("one hipGraph replay per step (CSR build + forward + CE + backward + gradient pack"
+                                + ("), then the all-reduce and the fused Adam launch" if cap.collective_outside else " + fused Adam)"))
+                return tstep_replay, flat, ar
+            except Exception as ex:  # noqa: BLE001 - whatever the runtime refuses: measure the eager step instead
+                ar["launch"] = f"eager launches from Python (capture failed: {ex})"
+                torch.cuda.synchronize()
 
         def tstep():
             clear_topology_cache()
@@ -354,7 +387,7 @@ def main():
         evs = ar_events["events"][-a.steps:]
         torch.cuda.synchronize()
         t_train, train_steps = elapsed, a.steps
-        ar_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / max(1, len(evs))
+        ar_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / max(1, len(evs)) if evs else 0.0
         collectives = flat_params.reducer.collectives - coll0
     elif a.train_steps > 0:
         tstep, flat_params, ar_events = make_train_step()
@@ -369,7 +402,7 @@ def main():
         fence()
         t_train, train_steps = time.perf_counter() - tt0, a.train_steps
         topology.check_deferred()
-        ar_ms = sum(e0.elapsed_time(e1) for e0, e1 in ar_events["events"]) / train_steps
+        ar_ms = sum(e0.elapsed_time(e1) for e0, e1 in ar_events["events"]) / train_steps if ar_events["events"] else 0.0
         collectives = flat_params.reducer.collectives - c0
 
     stats = torch.tensor([elapsed, t_train, ar_ms, float(batch.num_edges), float(batch.num_graphs), float(batch.num_nodes)],
@@ -399,9 +432,10 @@ def main():
                 pmc = json.load(f)
             traffic = pmc["kernels"].get(pmc.get("k1", ""), {}).get("hbm_bytes_per_launch")
             mlp_traffic = pmc["kernels"].get(pmc.get("dominant_mlp", ""), {}).get("hbm_bytes_per_launch")
-        mlp_name = max((k for k in ksum if k.startswith("mlp_fused")), key=lambda k: ksum[k]["avg_ms"] * ksum[k]["launches"])
-        mlp = ksum[mlp_name]
-        mlp_tflops = mlp["avg_work"] / (mlp["avg_ms"] * 1e-3) / 1e12
+        mlp_names = [k for k in ksum if k.startswith("mlp_fused")]  # none when the timed step was a hipGraph replay
+        mlp_name = max(mlp_names, key=lambda k: ksum[k]["avg_ms"] * ksum[k]["launches"]) if mlp_names else None
+        mlp = ksum[mlp_name] if mlp_name else None
+        mlp_tflops = mlp["avg_work"] / (mlp["avg_ms"] * 1e-3) / 1e12 if mlp else None
         result = {
             "metric": "edges aggregated/sec (GraphNet forward)" if a.mode == "forward" else
                       "edges aggregated/sec (GraphNet+classifier training step: fwd+bwd+allreduce+Adam)",
@@ -424,7 +458,7 @@ def main():
                                            "(not measured in this run)" if traffic is not None else None,
                          "avg_launch_ms": k1["avg_ms"], "launches": k1["launches"],
                          "algorithmic_bytes_per_launch": k1["avg_work"]},
-            "roofline_mlp": {"kernel": f"mlp_fused_kernel ({mlp_name}: fused gather+concat+MLP+LayerNorm+residual)",
+            "roofline_mlp": None if mlp is None else {"kernel": f"mlp_fused_kernel ({mlp_name}: fused gather+concat+MLP+LayerNorm+residual)",
                              "bound": "mfma", "achieved": mlp_tflops, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": mlp_tflops / MFMA_F32_PEAK_TFLOPS, "avg_launch_ms": mlp["avg_ms"],
                              "launches": mlp["launches"], "executed_flops_per_launch": mlp["avg_work"],
@@ -446,6 +480,13 @@ def main():
             "kernel_ms_per_step": {k: v["avg_ms"] * v["launches"] / ksteps for k, v in ksum.items()
                                    if not (k1_isolated and k.startswith("scatter_sum_csr"))},
         }
+        if mlp_names and a.mode == "forward":  # the whole step against the same roof: every MLP launch's executed FLOPs over the step's wall time
+            step_flops = sum(ksum[k]["avg_work"] * ksum[k]["launches"] for k in mlp_names) / ksteps
+            result["whole_step"] = {"executed_flops_per_step": step_flops, "achieved": step_flops / (elapsed / a.steps) / 1e12,
+                                    "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": step_flops / (elapsed / a.steps) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                                    "note": "all fused-MLP launches of one step (this rank) / ms_per_step; includes the CSR build and "
+                                            "every non-MFMA launch in the denominator"}
         if a.mode == "forward":
             result["step_launch"] = (f"one hipGraph replay per step (captured after the warm-up; per-kernel HIP events from {ksteps} eager "
                                      "steps after the timed region)") if graph is not None else \
@@ -456,9 +497,10 @@ def main():
                 "steps": train_steps, "ms_per_step": t_train / train_steps * 1e3,
                 "value": tot_edges * n_blocks * train_steps / t_train, "unit": "edges/s",
                 "graphs_per_sec": tot_graphs * train_steps / t_train,
-                "allreduce_ms": ar_ms if world > 1 else 0.0, "gradient_pack_ms": ar_ms if world == 1 else None,
+                "allreduce_ms": ar_ms if world > 1 else 0.0, "gradient_pack_ms": (ar_ms if ar_events["events"] else None) if world == 1 else None,
                 "allreduce_bytes": flat_params.grad.numel() * 4, "collectives_per_step": collectives / train_steps,
-                "backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None}
+                "backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None,
+                "step_launch": ar_events["launch"]}
         result["config"]["topology_validation"] = ("deferred: the out-of-range flags of each step's CSR build stay on the device and are "
                                                     "read once after the timed region" if a.validation == "deferred" else
                                                     "sync: flags read back (one host sync) inside every step")

@@ -93,7 +93,7 @@ class _FusedMLP(torch.autograd.Function):
         acts = [] if (meta.training and any(ctx.needs_input_grad) and HIP_BACKWARD) else None
         out = native.mlp_forward(list(zip(tables, meta.indices)), list(weights), list(biases), ln=ln,
                                  activation=meta.activation, act_param=meta.act_param, residual=residual, rows=meta.rows,
-                                 save_act=acts)
+                                 save_act=acts, save_need_dx=any(ctx.needs_input_grad[1:1 + s]))
         ctx.meta = meta
         # the saved post-activations go through save_for_backward like the inputs: autograd then frees them as soon as this
         # node's backward has run (held as plain attributes they lived until the whole graph died: +30 GB at c5)
@@ -157,8 +157,11 @@ def _fused_mlp_backward_hip(meta: _MlpMeta, args, need, grad_out, saved_act=None
             gk = r["dx"][:, off:off + w]
             if idx is None:
                 grads[k] = gk
-            else:  # rows gathered by index: scatter the row gradients back (rare, operator-level API only)
-                grads[k] = torch.zeros_like(t).index_add_(0, idx.long(), gk)
+            else:  # rows gathered by index (operator-level API only): sum the row gradients per table row with K1 through
+                # the index's own destination CSR - stable order, no float atomics, bitwise reproducible
+                from .topology import get_destination_csr
+                csr = get_destination_csr(idx, t.size(0), t.device)
+                grads[k] = native.scatter_sum_csr(gk, csr.rowptr, csr.perm, t.size(0))
         off += w
     # weights and biases: dW_l = dz_l^T (input of Linear l), db_l = column sums of dz_l
     for k in range(l):
@@ -231,7 +234,7 @@ class _EdgeProcessorWSplit(torch.autograd.Function):
                                  activation=activation, act_param=act_param, residual=e, rows=e.size(0),
                                  modes=[native.SEG_ADD, native.SEG_ADD, native.SEG_MATMUL],
                                  aggregate=(topo.dst_sorted, topo.rowptr, topo.num_nodes) if with_agg else None,
-                                 save_act=acts)
+                                 save_act=acts, save_need_dx=bool(ctx.needs_input_grad[3]))
         # kept for the backward through save_for_backward (freed when this node's backward has run): the projections - its
         # gathered inputs again, [N, H] each - and the post-activations
         extra = ([ps, pd] + acts) if training else []

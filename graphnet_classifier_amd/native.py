@@ -426,16 +426,17 @@ def _prepare_mlp(segments, weights, biases, residual, rows, modes):
 SAVE_ACT = os.environ.get("GNC_NO_SAVED_ACT") is None  # A/B switch: training forwards keep nothing, backwards recompute
 
 
-def _backward_reads_saved_act(lib, desc, any_tensor) -> bool:
+def _backward_reads_saved_act(lib, desc, any_tensor, need_dx: bool = True) -> bool:
     """Would gnc_mlp_backward_f32 read saved post-activations for this description?  (Shape question only: the K8 kernel
     of some shapes - the weights-resident data kernel of the node processors - recomputes regardless, and a forward that
-    saved for it would write tensors nobody reads.)"""
+    saved for it would write tensors nobody reads.)  ``need_dx``: whether that backward will be asked for the input
+    gradient (the kernel choice, and with it the answer, depends on it)."""
     bd = MlpBwdDesc()
     ctypes.memmove(ctypes.byref(bd.fwd), ctypes.byref(desc), ctypes.sizeof(MlpDesc))
     ptr = any_tensor.data_ptr()  # any 16-B aligned device address: the query looks at alignment only
     for l in range(desc.num_linear - 1):
         bd.act[l] = ptr
-    bd.act_given, bd.dx = 1, ptr
+    bd.act_given, bd.dx = 1, (ptr if need_dx else None)
     if lib.gnc_mlp_backward_fused_rows(ctypes.byref(bd.fwd)) > 0:
         bd.dw_partial[0] = ptr
     return lib.gnc_mlp_backward_saved_act_honoured(ctypes.byref(bd)) == 1
@@ -443,7 +444,7 @@ def _backward_reads_saved_act(lib, desc, any_tensor) -> bool:
 
 def mlp_forward(segments, weights, biases, ln=None, activation: str = "ReLU", act_param: float = 0.0,
                 residual: torch.Tensor | None = None, rows: int | None = None, modes=None, aggregate=None,
-                save_act: list | None = None):
+                save_act: list | None = None, save_need_dx: bool = True):
     """Fused MLP.  segments (in CONCAT order): list of (table [*, w] fp32, index int32 [rows] | None);
     ``modes[s]`` is SEG_MATMUL (default) or SEG_ADD.  Weights may be column slices of a larger
     matrix.  The segment that is also the residual is listed last for the kernel (its weight
@@ -456,14 +457,15 @@ def mlp_forward(segments, weights, biases, ln=None, activation: str = "ReLU", ac
 
     ``save_act`` (training forward): an empty list; when the kernel that serves the call can write the post-activation
     outputs of its hidden layers (gnc_mlp_save_act_supported) they are appended to it ([rows, H] each) for
-    ``mlp_backward(saved_act=...)``, which then reads them instead of recomputing the forward of every tile."""
+    ``mlp_backward(saved_act=...)``, which then reads them instead of recomputing the forward of every tile;
+    ``save_need_dx`` says whether that backward will want the input gradient (``need_dx``)."""
     lib = load_library()
     segs, weights, biases, residual, rows, modes = _prepare_mlp(segments, weights, biases, residual, rows, modes)
     dev = segs[0][0].device
     out = torch.empty(rows, weights[-1].size(0), dtype=torch.float32, device=dev)
     desc = make_mlp_desc(segs, weights, biases, ln, activation, act_param, residual, out, rows)
     if (save_act is not None and SAVE_ACT and rows > 0 and len(weights) >= 2
-            and lib.gnc_mlp_save_act_supported(ctypes.byref(desc)) == 0 and _backward_reads_saved_act(lib, desc, out)):
+            and lib.gnc_mlp_save_act_supported(ctypes.byref(desc)) == 0 and _backward_reads_saved_act(lib, desc, out, save_need_dx)):
         for l in range(len(weights) - 1):
             a = torch.empty(rows, weights[l].size(0), dtype=torch.float32, device=dev)
             desc.save_act[l] = a.data_ptr()
@@ -554,7 +556,12 @@ def mlp_backward(segments, weights, biases, ln, grad_out: torch.Tensor | None, r
         gt, gi = _vector_rows(_rowmajor(grad_gather[0])), grad_gather[1]
         bd.grad_gather, bd.ld_grad_gather = gt.data_ptr(), _ld(gt)
         bd.grad_gather_index, bd.grad_gather_rows = gi.data_ptr(), gt.size(0)
-        if lib.gnc_mlp_backward_grad_gather_honoured(ctypes.byref(bd)) != 1:  # gather in front of the launch (K2)
+        # the residual's gradient is the EFFECTIVE output gradient: when the kernel cannot fold it into dx itself (the
+        # residual went through a padded copy: width % 4 != 0), the caller adds it and needs the rows as a tensor
+        res_fold = (mm[-1][1] is None and residual is not None and mm[-1][0].data_ptr() == residual.data_ptr()
+                    and mm[-1][2] == w[-1].size(0))
+        caller_adds_residual = residual is not None and need_dx and not res_fold
+        if caller_adds_residual or lib.gnc_mlp_backward_grad_gather_honoured(ctypes.byref(bd)) != 1:  # gather in front of the launch (K2)
             grad_out = gather_rows(gt, gi) if grad_out is None else gather_rows_add(gt, gi, _rowmajor(grad_out))
             bd.grad_gather = bd.grad_gather_index = None
             bd.ld_grad_gather = bd.grad_gather_rows = 0

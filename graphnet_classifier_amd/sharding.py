@@ -82,11 +82,13 @@ class FlatGradAllReduce:
         for p in self.params:
             p.grad = None
 
-    def pack(self) -> torch.Tensor:
-        """Bring every gradient into the flat buffer and make ``p.grad`` the view of it."""
+    def pack(self, grads=None) -> torch.Tensor:
+        """Bring every gradient into the flat buffer and make ``p.grad`` the view of it.  ``grads``: the gradients
+        (one per parameter, None = unused) when they did not land in ``p.grad`` - a step that differentiated private
+        leaf aliases of the parameters (train.CapturedTrainStep) hands them over here."""
         srcs, dsts = [], []
-        for p, v in zip(self.params, self.views):
-            g = p.grad
+        for k, (p, v) in enumerate(zip(self.params, self.views)):
+            g = p.grad if grads is None else grads[k]
             if g is None:
                 v.zero_()  # parameter unused by this step's graph
             elif g.data_ptr() != v.data_ptr():
@@ -97,12 +99,18 @@ class FlatGradAllReduce:
             torch._foreach_copy_(dsts, srcs)
         return self.flat
 
-    def __call__(self) -> torch.Tensor | None:
+    def __call__(self, grads=None) -> torch.Tensor | None:
         """Call between backward() and optimizer.step(); returns the flat (reduced) buffer."""
         world = _world(self.group)
         if world == 1 and not self.pack_always:
             return None
-        self.pack()
+        self.pack(grads)
+        return self.allreduce()
+
+    def allreduce(self) -> torch.Tensor:
+        """The collective alone, over an already packed buffer (a step whose forward + backward + pack replay from a
+        hipGraph issues it directly after the replay)."""
+        world = _world(self.group)
         if world > 1:
             if self.flat.is_cuda and dist.get_backend(self.group) == "gloo":  # CPU rehearsal backend: stage through the host
                 host = self.flat.cpu()

@@ -45,14 +45,20 @@ def set_validation(mode: str) -> None:
 
 
 def check_deferred() -> None:
-    """Read every pending out-of-range flag (one host sync) and raise the IndexError a synchronous build would have."""
+    """Read every pending out-of-range flag (one host sync) and raise the IndexError a synchronous build would have.
+    A topology whose flag is set is evicted from the caches first, so a later call with the same ``edge_index`` builds
+    (and reports) it again instead of hitting an entry whose flag nobody will read a second time."""
     global _pending
     flags, _pending = _pending, []
     if flags:
         bad = torch.stack([f.any() for f, _ in flags]).tolist()
-        for is_bad, (_, n) in zip(bad, flags):
+        first = None
+        for is_bad, (status, n) in zip(bad, flags):
             if is_bad:
-                raise IndexError(f"edge_index has node ids outside [0, {n})")
+                _default_cache.evict_status(status)
+                first = n if first is None else first
+        if first is not None:
+            raise IndexError(f"edge_index has node ids outside [0, {first})")
 
 
 class GraphTopology:
@@ -81,7 +87,8 @@ class GraphTopology:
         mode = _VALIDATION if validate is True else validate
         if mode == "deferred":
             _pending.append((status, self.num_nodes))
-            if len(_pending) > 4096:
+            # bound the list; never from inside a hipGraph capture (the read-back is a host sync)
+            if len(_pending) > 4096 and not torch.cuda.is_current_stream_capturing():
                 check_deferred()
         elif mode:
             # one host sync per topology build; the reference syncs on every scatter
@@ -151,7 +158,14 @@ class TopologyCache:
         if hit is not None:
             self._entries.move_to_end(key)
             self.hits += 1
-            return hit[0]
+            topo = hit[0]
+            if topo.deferred and _VALIDATION == "sync":
+                # built without a read-back, asked for again in synchronous mode: read its flags now (one sync, once)
+                topo.deferred = False
+                if any(topo.status.tolist()):
+                    del self._entries[key]
+                    raise IndexError(f"edge_index has node ids outside [0, {topo.num_nodes})")
+            return topo
         self.misses += 1
         topo = GraphTopology(edge_index, num_nodes, device=device)
         self._entries[key] = (topo, edge_index if edge_index.is_cuda else None)
@@ -161,6 +175,12 @@ class TopologyCache:
 
     def clear(self):
         self._entries.clear()
+
+    def evict_status(self, status: torch.Tensor) -> None:
+        """Drop the entry whose topology owns ``status`` (check_deferred: its flag was set)."""
+        for key, (topo, _) in list(self._entries.items()):
+            if getattr(topo, "status", None) is status:
+                del self._entries[key]
 
 
 _default_cache = TopologyCache()

@@ -4,7 +4,7 @@
 signature and observable behaviour: Adam(lr=1e-3) (:9), CrossEntropyLoss (:10), one optimizer step per sample in
 dataset order (:35-45), average training loss per epoch, early stopping on it (:57-69), ``best_model_epoch{k}.pth``
 / ``final_model.pth`` (:61-62, :72-73) and the timestamped log file with the reference's line formats (:22-30,
-:52-54, :76-80).  What differs is how a step runs:
+:52-54, :76-80).  What differs is how a step runs and how the run is organised:
 
 * parameters and gradients are views of two flat fp32 buffers (``FlatParameters``), the optimizer is ONE fused Adam
   launch over them (``FusedAdam`` -> ``gnc_adam_step_f32``) instead of a walk over 76 tensors;
@@ -13,7 +13,9 @@ dataset order (:35-45), average training loss per epoch, early stopping on it (:
 * when consecutive samples share one topology (pixel / patch graphs: the edge list depends on the image size only,
   utils/image_to_graph/image_to_graph_optimized.py:42-47) the whole step - forward, loss, backward, gradient pack,
   Adam - is captured into a hipGraph once and replayed per sample (``CapturedTrainStep``): one launch per step
-  instead of ~150.
+  instead of ~150;
+* the run's side effects live in three small objects: ``RunJournal`` (the log file and the console lines),
+  ``PlateauStopper`` (best loss so far, epochs without improvement) and ``CheckpointShelf`` (the ``.pth`` files).
 
 Saved ``.pth`` files hold CPU tensors under the reference's state-dict keys, so they load in the reference as they
 are (``utils/inference.py:40-45``) and vice versa.
@@ -25,6 +27,7 @@ import time
 from datetime import datetime
 
 import torch
+import torch.distributed as dist
 import torch.nn as nn
 
 from . import native
@@ -51,7 +54,9 @@ class FlatParameters:
     construct this last."""
 
     def __init__(self, module: nn.Module, group=None, average: bool = True):
-        self.params = [p for p in module.parameters() if p.requires_grad]
+        named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
+        self.names = [n for n, _ in named]
+        self.params = [p for _, p in named]
         if not self.params:
             raise ValueError("module has no trainable parameters")
         dev = require_gpu_param(self.params[0], "FlatParameters")
@@ -97,10 +102,11 @@ class FusedAdam:
     def zero_grad(self, set_to_none: bool = True) -> None:
         self.fp.reducer.zero_grad()
 
-    def step(self, reduce: bool = True) -> None:
-        """Gradient pack (+ the one all-reduce when a process group with more than one rank is up) and the update."""
+    def step(self, reduce: bool = True, grads=None) -> None:
+        """Gradient pack (+ the one all-reduce when a process group with more than one rank is up) and the update.
+        ``grads``: see FlatGradAllReduce.pack."""
         if reduce:
-            self.fp.reducer()
+            self.fp.reducer(grads)
         native.adam_step(self.fp.flat, self.fp.grad, self.exp_avg, self.exp_avg_sq, self.step_count, self._scratch, self.lr,
                          self.betas[0], self.betas[1], self.eps, self.weight_decay)
 
@@ -116,58 +122,249 @@ def _same_topology(a: torch.Tensor, b: torch.Tensor) -> bool:
     return a is b or (a.shape == b.shape and a.dtype == b.dtype and a.device == b.device and bool(torch.equal(a, b)))
 
 
+def _world(group=None) -> int:
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+class _Through(nn.Module):
+    """``functional_call`` target: runs ``fn(model, *args)`` with the model's parameters swapped for the given ones."""
+
+    def __init__(self, model: nn.Module, fn):
+        super().__init__()
+        self.model, self.fn = model, fn
+
+    def forward(self, *args):
+        return self.fn(self.model, *args)
+
+
 class CapturedTrainStep:
     """One training step (utils/train_model.py:37-42: forward, CE loss, zero_grad, backward, Adam) for ONE fixed
     topology, captured into a hipGraph and replayed per sample.  The loss of every replay is added to ``loss_sum``
-    (device float64) inside the graph.  Warm-up steps run before the capture; parameters and optimizer state are
-    restored afterwards, so constructing this object does not train."""
+    (device float64) inside the graph.  Warm-up steps run before the capture; parameters, optimizer state, module
+    buffers and the loss accumulator are restored afterwards, so constructing this object does not train.
 
-    def __init__(self, model: nn.Module, optimizer: FusedAdam, criterion, sample, label, loss_sum: torch.Tensor):
+    **Safe whatever the caller ran before.**  A parameter's ``AccumulateGrad`` node remembers the stream that was
+    current when the node was created, and the node lives as long as ANY autograd graph that reached the parameter
+    (a ``loss`` tensor the caller still holds is enough).  Had the caller trained eagerly on the legacy default
+    stream, a backward inside the capture would find those nodes, and the autograd engine would make the legacy
+    stream wait on an event of the capturing stream and accumulate there: a default-stream operation in the middle
+    of a stream capture, which takes the HIP runtime down at ``hipStreamEndCapture`` (tools/repro_capture3.py
+    reproduces it in plain PyTorch: MODE=stale_default crashes, fresh_default / stale_side / alias_default do not).
+    The captured step therefore never differentiates the module's own parameter tensors: it runs the module through
+    ``torch.func.functional_call`` on PRIVATE leaf aliases over the same storage (views of the flat buffer), whose
+    autograd nodes are born on the warm-up / capture stream and die with each step's graph, and hands their gradients
+    to the reducer's pack.  Nothing of the caller's autograd history is reachable from the capture.
+
+    ``forward(model, x, pos, edge_index) -> logits`` replaces the default ``model((x, pos, edge_index))`` (a batched
+    read-out, for instance); ``loss_scale`` multiplies the loss (``1 / global graph count`` of a sharded batch).
+    With a process group of more than one rank the graph holds forward + backward + gradient pack, and every call
+    issues the ONE all-reduce and the fused Adam launch directly after the replay."""
+
+    def __init__(self, model: nn.Module, optimizer: FusedAdam, criterion, sample, label, loss_sum: torch.Tensor, *,
+                 forward=None, loss_scale: float = 1.0, capture_error_mode: str = "global"):
         x, pos, edge_index = sample
         dev = require_gpu_param(next(model.parameters()), "CapturedTrainStep")
+        fp = optimizer.fp
+        self.optimizer = optimizer
         self.edge_index_host = edge_index
         self.x = x.to(device=dev, dtype=torch.float32).clone()
         self.pos = pos.to(device=dev, dtype=torch.float32).clone()
         self.edge_index = edge_index.to(dev)
         self.label = torch.as_tensor(label).to(dev).clone()
         self.loss_sum = loss_sum
+        self.collective_outside = _world(fp.reducer.group) > 1
         from .topology import get_topology
         # the build's host sync happens here, outside the capture; the reference keeps the CSR arrays alive for the graph
         self.topo = get_topology(self.edge_index, self.x.size(0), dev)
 
+        fwd = forward if forward is not None else (lambda mod, xx, pp, ee: mod((xx, pp, ee)))
+        through = _Through(model, fwd)
+        # private leaves over the parameters' storage (the flat buffer): see the class docstring
+        wanted = dict(zip(fp.names, range(len(fp.names))))
+        alias, self._leaves = {}, [None] * len(fp.names)
+        for name, p in model.named_parameters():
+            leaf = p.detach()
+            if name in wanted:
+                leaf.requires_grad_(True)
+                self._leaves[wanted[name]] = leaf
+            alias["model." + name] = leaf
+        if any(l is None for l in self._leaves):
+            raise RuntimeError("CapturedTrainStep: the optimizer's FlatParameters were built over another module")
+        leaves = self._leaves
+
         def one_step():
-            logits = model((self.x, self.pos, self.edge_index))
+            logits = torch.func.functional_call(through, alias, (self.x, self.pos, self.edge_index))
             loss = criterion(logits, self.label)
-            optimizer.zero_grad()
-            loss.backward()
-            optimizer.step()
+            if loss_scale != 1.0:
+                loss = loss * loss_scale
+            for leaf in leaves:                                                        # utils/train_model.py:40
+                leaf.grad = None
+            loss.backward()                                                            # :41
+            grads = [leaf.grad for leaf in leaves]
+            if self.collective_outside:
+                fp.reducer.pack(grads)
+            else:
+                optimizer.step(grads=grads)                                            # :42 (pack + fused Adam)
             self.loss_sum.add_(loss.detach().double())
 
         snap = optimizer.state_snapshot()
+        buffers = [(b, b.clone()) for b in model.buffers()]  # BatchNorm statistics must not absorb the warm-up either
         keep = self.loss_sum.clone()
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             for _ in range(3):  # kernel attributes, allocator pools, lazily built source-sorted CSR
                 one_step()
+                if self.collective_outside:
+                    self._finish()
         torch.cuda.current_stream(dev).wait_stream(side)
-        optimizer.zero_grad()
+        for leaf in leaves:
+            leaf.grad = None
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode=capture_error_mode):
             one_step()
         optimizer.state_restore(snap)
+        with torch.no_grad():
+            for b, saved in buffers:
+                b.copy_(saved)
         self.loss_sum.copy_(keep)
+
+    def _finish(self) -> None:
+        """Multi-rank tail of a step: the ONE collective over the packed flat buffer, then the fused Adam launch."""
+        self.optimizer.fp.reducer.allreduce()
+        self.optimizer.step(reduce=False)
 
     def matches(self, sample) -> bool:
         x, pos, edge_index = sample
         return x.shape == self.x.shape and pos.shape == self.pos.shape and _same_topology(edge_index, self.edge_index_host)
+
+    def replay(self) -> None:
+        """The step on whatever the captured input buffers hold (``self.x`` / ``self.pos`` / ``self.label``)."""
+        self.graph.replay()
+        if self.collective_outside:
+            self._finish()
 
     def __call__(self, sample, label) -> None:
         x, pos, _ = sample
         self.x.copy_(x, non_blocking=True)
         self.pos.copy_(pos, non_blocking=True)
         self.label.copy_(torch.as_tensor(label), non_blocking=True)
-        self.graph.replay()
+        self.replay()
+
+
+# --------------------------------------------------------------------------- the run's side effects
+class RunJournal:
+    """Everything the reference's train() writes or prints besides checkpoints: the timestamped
+    ``training_logs_<stamp>.txt`` (header :26-30, two lines per epoch :52-54, footer :76-80) and the console lines
+    (:19, :48, :50, :63, :68, :74).  The line formats are contract (golden G8 compares them)."""
+
+    RULE = "-" * 50
+
+    def __init__(self, directory: str, epochs: int, patience: int):
+        os.makedirs(directory, exist_ok=True)
+        print(f"Training model in {directory}")
+        opened = datetime.now()
+        self.epochs = epochs
+        self.path = os.path.join(directory, f"training_logs_{opened.strftime('%Y%m%d_%H%M%S')}.txt")
+        self._append([f"Training started at: {opened.strftime('%Y-%m-%d %H:%M:%S')}", f"Epochs: {epochs}, Patience: {patience}",
+                      f"Output path: {directory}", self.RULE], mode="w")
+
+    def _append(self, lines, mode: str = "a") -> None:
+        with open(self.path, mode) as f:
+            f.write("".join(line + "\n" for line in lines))
+
+    def epoch(self, number: int, avg_loss: float, seconds: float) -> None:
+        tag = f"Epoch {number}/{self.epochs}"
+        print(f"{tag}, avg_loss={avg_loss:.4f}")
+        print(f"epoch: {number} needed {seconds} time")
+        self._append([f"{tag}, avg_loss={avg_loss:.4f}", f"{tag}, needed {seconds / 60:.2f} minutes"])
+
+    def saved(self, kind: str, path: str) -> None:
+        print(f"Saved {kind} model: {path}")
+
+    def stopped_early(self, number: int) -> None:
+        print(f"Early stopping at epoch {number}")
+
+    def close(self, best_loss: float, final_path: str) -> None:
+        self._append([self.RULE, f"Training completed at: {datetime.now().strftime('%Y-%m-%d %H:%M:%S')}",
+                      f"Best loss achieved: {best_loss:.4f}", f"Final model saved: {final_path}"])
+
+
+class PlateauStopper:
+    """Early stopping on the average TRAINING loss (utils/train_model.py:57-69): an epoch either sets a new best (strictly
+    lower) or counts as stale; ``patience`` stale epochs in a row end the run."""
+
+    def __init__(self, patience: int):
+        self.patience, self.best, self.stale = patience, float("inf"), 0
+
+    def observe(self, value: float) -> bool:
+        """True when ``value`` is a new best."""
+        if value < self.best:
+            self.best, self.stale = value, 0
+            return True
+        self.stale += 1
+        return False
+
+    @property
+    def exhausted(self) -> bool:
+        return self.stale >= self.patience
+
+
+class CheckpointShelf:
+    """The ``.pth`` files of a run (:61-62, :72-73): state dicts under the reference's keys, CPU tensors."""
+
+    def __init__(self, model: nn.Module, directory: str):
+        self.model, self.directory = model, directory
+
+    def _write(self, filename: str) -> str:
+        path = os.path.join(self.directory, filename)
+        torch.save({k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()}, path)
+        return path
+
+    def best(self, epoch_number: int) -> str:
+        return self._write(f"best_model_epoch{epoch_number}.pth")
+
+    def final(self) -> str:
+        return self._write("final_model.pth")
+
+
+class _SampleStepper:
+    """Runs one optimizer step per sample: eagerly, or - once two consecutive samples have shared a topology - as a
+    replay of the captured step."""
+
+    def __init__(self, model, optimizer, criterion, loss_sum, device, capture: bool):
+        self.model, self.optimizer, self.criterion, self.loss_sum, self.device = model, optimizer, criterion, loss_sum, device
+        self.capture = capture
+        self.captured: CapturedTrainStep | None = None
+        self._previous = None
+
+    def _try_replay(self, sample, label) -> bool:
+        if self.captured is None and self._previous is not None and self._previous[0].shape == sample[0].shape \
+                and _same_topology(self._previous[2], sample[2]):
+            self.captured = CapturedTrainStep(self.model, self.optimizer, self.criterion, sample, label, self.loss_sum)
+        if self.captured is not None and self.captured.matches(sample):
+            self.captured(sample, label)
+            return True
+        self._previous = sample
+        return False
+
+    def __call__(self, sample, label) -> None:
+        dev = self.device
+        is_graph = isinstance(sample, (tuple, list)) and len(sample) == 3
+        if self.capture and is_graph and self._try_replay(sample, label):
+            return
+        if is_graph:
+            # edge_index stays where it is: a host tensor is looked up in the topology cache by content, so equal
+            # topologies are sorted once, not once per sample
+            sample = (sample[0].to(dev, non_blocking=True), sample[1].to(dev, non_blocking=True), sample[2])
+        else:
+            sample = sample.to(dev, non_blocking=True)
+        logits = self.model(sample)                                                            # utils/train_model.py:37
+        loss = self.criterion(logits, torch.as_tensor(label).to(dev, non_blocking=True))      # :38
+        self.optimizer.zero_grad()                                                             # :40
+        loss.backward()                                                                        # :41
+        self.optimizer.step()                                                                  # :42
+        self.loss_sum += loss.detach().double()                                                # :44, without the per-sample sync
 
 
 def train(model, dataset, epochs, patience=5, output_path='weights', start_weights=None, *, capture: bool = True, lr: float = 1e-3):
@@ -176,101 +373,42 @@ def train(model, dataset, epochs, patience=5, output_path='weights', start_weigh
     if start_weights:
         model.load_state_dict(torch.load(start_weights, map_location="cpu"))           # :14-15
     dev = require_gpu_param(next(model.parameters()), "train")
-    flat = FlatParameters(model)
-    optimizer = FusedAdam(flat, lr=lr)                                                 # :9
+    optimizer = FusedAdam(FlatParameters(model), lr=lr)                                # :9
     criterion = nn.CrossEntropyLoss()                                                  # :10
-
-    os.makedirs(output_path, exist_ok=True)                                            # :18
-    print(f"Training model in {output_path}")
-    timestamp = datetime.now().strftime("%Y%m%d_%H%M%S")
-    log_path = os.path.join(output_path, f'training_logs_{timestamp}.txt')
-    with open(log_path, "w") as the_file:                                              # :26-30
-        the_file.write(f"Training started at: {datetime.now().strftime('%Y-%m-%d %H:%M:%S')}\n")
-        the_file.write(f"Epochs: {epochs}, Patience: {patience}\n")
-        the_file.write(f"Output path: {output_path}\n")
-        the_file.write("-" * 50 + "\n")
-
-    def save(path):
-        torch.save({k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, path)
-
+    journal = RunJournal(output_path, epochs, patience)
+    shelf = CheckpointShelf(model, output_path)
+    stopper = PlateauStopper(patience)
     loss_sum = torch.zeros((), dtype=torch.float64, device=dev)
+    # this loop steps one rank's model on its own samples: with a multi-rank process group up, a captured step would
+    # record (or, under gloo, host-stage) a collective per sample that nothing here asked for
+    stepper = _SampleStepper(model, optimizer, criterion, loss_sum, dev, capture and _world() == 1)
     history = []
-    # The whole loop runs on a side stream.  A hipGraph capture that follows eager autograd steps issued on the
-    # legacy default stream takes the HIP runtime down at hipStreamEndCapture (reproduced: tools/repro_capture2.py,
-    # MODE=eager_first segfaults, MODE=eager_side does not); PyTorch's whole-network capture recipe asks for a
-    # side-stream warm-up for the same reason.  Nothing here depends on the default stream.
+    # Belt and braces: the loop runs on a side stream, so that the eager steps in front of a capture never touch the
+    # legacy default stream.  The capture itself no longer depends on it (CapturedTrainStep differentiates private
+    # aliases of the parameters, see its docstring for the hipStreamEndCapture crash this used to be the only guard of).
     run_stream = torch.cuda.Stream(device=dev)
     run_stream.wait_stream(torch.cuda.current_stream(dev))
     try:
         with torch.cuda.stream(run_stream):
-            return _train_loop(model, dataset, epochs, patience, output_path, dev, optimizer, criterion, capture, log_path, save,
-                               loss_sum, history)
+            for epoch in range(1, epochs + 1):
+                started = time.time()
+                loss_sum.zero_()
+                steps = 0
+                for sample, label in dataset:                                          # :35
+                    stepper(sample, label)
+                    steps += 1
+                avg_loss = float(loss_sum.item()) / max(1, steps)                      # :47 (the epoch's one host sync)
+                history.append(avg_loss)
+                journal.epoch(epoch, avg_loss, time.time() - started)
+                if stopper.observe(avg_loss):                                          # :57-66
+                    journal.saved("best", shelf.best(epoch))
+                if stopper.exhausted:                                                  # :67-69
+                    journal.stopped_early(epoch)
+                    break
+            final_path = shelf.final()                                                 # :72-74
+            journal.saved("final", final_path)
+            journal.close(stopper.best, final_path)
     finally:
         torch.cuda.current_stream(dev).wait_stream(run_stream)
-
-
-def _train_loop(model, dataset, epochs, patience, output_path, dev, optimizer, criterion, capture, log_path, save, loss_sum, history):
-    best_loss = float('inf')
-    patience_counter = 0
-    captured: CapturedTrainStep | None = None
-    prev_sample = None
-    for epoch in range(epochs):
-        checkpoint1 = time.time()
-        loss_sum.zero_()
-        num_batches = 0
-        for sample, label in dataset:                                                  # :35
-            graph_sample = isinstance(sample, (tuple, list)) and len(sample) == 3
-            if capture and graph_sample:
-                if captured is None and prev_sample is not None and prev_sample[0].shape == sample[0].shape \
-                        and _same_topology(prev_sample[2], sample[2]):
-                    captured = CapturedTrainStep(model, optimizer, criterion, sample, label, loss_sum)
-                if captured is not None and captured.matches(sample):
-                    captured(sample, label)
-                    num_batches += 1
-                    continue
-                prev_sample = sample
-            if graph_sample:
-                # edge_index stays where it is: a host tensor is looked up in the topology cache by content, so equal
-                # topologies are sorted once, not once per sample
-                sample = (sample[0].to(dev, non_blocking=True), sample[1].to(dev, non_blocking=True), sample[2])
-            else:
-                sample = sample.to(dev, non_blocking=True)
-            logits = model(sample)                                                     # :37
-            loss = criterion(logits, torch.as_tensor(label).to(dev, non_blocking=True))  # :38
-            optimizer.zero_grad()                                                      # :40
-            loss.backward()                                                            # :41
-            optimizer.step()                                                           # :42
-            loss_sum += loss.detach().double()                                         # :44, without the per-sample sync
-            num_batches += 1
-
-        avg_loss = float(loss_sum.item()) / max(1, num_batches)                        # :47 (the epoch's one host sync)
-        history.append(avg_loss)
-        print(f"Epoch {epoch+1}/{epochs}, avg_loss={avg_loss:.4f}")
-        checkpoint2 = time.time()
-        print(f"epoch: {epoch + 1} needed {checkpoint2 - checkpoint1} time")
-        with open(log_path, "a") as the_file:                                          # :52-54
-            the_file.write(f"Epoch {epoch+1}/{epochs}, avg_loss={avg_loss:.4f}\n")
-            the_file.write(f"Epoch {epoch+1}/{epochs}, needed {(checkpoint2 - checkpoint1) / 60:.2f} minutes\n")
-
-        if avg_loss < best_loss:                                                       # :57-66
-            best_loss = avg_loss
-            patience_counter = 0
-            best_model_path = os.path.join(output_path, f'best_model_epoch{epoch+1}.pth')
-            save(best_model_path)
-            print(f"Saved best model: {best_model_path}")
-        else:
-            patience_counter += 1
-        if patience_counter >= patience:                                               # :67-69
-            print(f"Early stopping at epoch {epoch+1}")
-            break
-
-    final_model_path = os.path.join(output_path, 'final_model.pth')                    # :72-74
-    save(final_model_path)
-    print(f"Saved final model: {final_model_path}")
-    with open(log_path, "a") as the_file:                                              # :76-80
-        the_file.write("-" * 50 + "\n")
-        the_file.write(f"Training completed at: {datetime.now().strftime('%Y-%m-%d %H:%M:%S')}\n")
-        the_file.write(f"Best loss achieved: {best_loss:.4f}\n")
-        the_file.write(f"Final model saved: {final_model_path}\n")
-    return {"avg_loss": history, "best_loss": best_loss, "log_path": log_path, "captured": captured is not None,
+    return {"avg_loss": history, "best_loss": stopper.best, "log_path": journal.path, "captured": stepper.captured is not None,
             "optimizer": optimizer}

@@ -316,10 +316,44 @@ def training_run():
     print("G8b:", sm.i, "steps;", files, keep, stdout)
 
 
+def default_model_gradients():
+    """G9: the DEFAULT model of main.py:72-73 (all widths 128, 3 blocks, CombinedModel read-out over 1024 nodes) on the
+    R = 32 pixel graph of a shipped image - the reference's real training regime (main.py:60: one such graph per
+    optimizer step) - through utils/train_model.py:37-41: logits, loss and ALL 76 parameter gradients, computed by the
+    reference's own classes.  Pins the 128-wide backward kernels against gradients the reference itself produced
+    (VERDICT round 2, item 4a).  Inputs are those of g4_graphnet_default.npz (same image, same builder)."""
+    sys.path.insert(0, REF)
+    _register_metalayer()
+    from models.GNN import CombinedModel, GraphNet
+    from utils.image_to_graph.image_to_graph_optimized import image_to_graph_pixel_optimized
+    img = os.path.join(REF, "static/muffin/img_4_880_32.jpg")
+    xi, posi, eii = image_to_graph_pixel_optimized(img, resize_value=32)
+    x = torch.tensor(xi, dtype=torch.float32)          # utils/dataloader.py:49-51
+    pos = torch.tensor(posi, dtype=torch.float32)
+    ei = torch.tensor(eii, dtype=torch.long)
+    torch.manual_seed(9)
+    m = CombinedModel(GraphNet(num_local_features=3, space_dim=2, out_channels=1, n_blocks=3), num_nodes=x.size(0), classes=2)
+    label = torch.tensor(1, dtype=torch.long)          # muffin = class 1 under ImageFolder's sorted class names
+    before = _sd(m, "before/")
+    crit = torch.nn.CrossEntropyLoss()
+    logits = m((x, pos, ei))                           # utils/train_model.py:37
+    loss = crit(logits, label)                         # :38
+    m.zero_grad()
+    loss.backward()                                    # :41
+    grads = {"grad/" + k: _np(p.grad) for k, p in m.named_parameters()}
+    assert len(grads) == 76
+    _save("g9_default_train_grads.npz", x=_np(x), pos=_np(pos), edge_index=_np(ei), label=_np(label), logits=_np(logits),
+          loss=_np(loss), **before, **grads)
+    print("G9: loss", float(loss), "logits", logits.tolist(), "max |grad|", max(float(np.abs(g).max()) for g in grads.values()))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "g8":
         training_run()
+    elif len(sys.argv) > 1 and sys.argv[1] == "g9":
+        default_model_gradients()
     else:
         main()
         image_graphs()
         training_run()
+        default_model_gradients()

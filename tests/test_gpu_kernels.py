@@ -675,3 +675,37 @@ def test_mlp_backward_wsplit_shape_matches_autograd(native, d):
             for li, k in enumerate(("m.model.0.weight", "m.model.2.weight", "m.model.4.weight")):
                 gw = sd64[k].grad
                 assert float((r["dw"][li].cpu().double() - gw).abs().max()) < 1e-4 * max(1.0, float(gw.abs().max())), (k, fused)
+
+
+def test_gathered_segment_gradient_runs_through_k1_and_is_reproducible(native):
+    """Operator-level concat form (MetaLayer's x[row], x[col] fused as gathered MATMUL segments): the gradient of a
+    gathered table is the per-row sum of the edge gradients.  It is formed by K1 through the index's own destination CSR
+    (no float atomics): equal to float64 autograd and bit-identical from run to run."""
+    from graphnet_classifier_amd import functional as Fn
+    rng = np.random.default_rng(77)
+    n, e, d = 97, 1501, 32
+    sd = _mlp_sd(rng, 3 * d, d, d, 2, True)
+    xs = torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32))
+    ea = torch.from_numpy(rng.standard_normal((e, d)).astype(np.float32))
+    src = torch.from_numpy(rng.integers(0, n, size=e).astype(np.int32))
+    dst = torch.from_numpy(rng.integers(0, n - 5, size=e).astype(np.int32))  # the last rows receive nothing
+    gout = torch.from_numpy(rng.standard_normal((e, d)).astype(np.float32))
+    x64, e64 = xs.double().requires_grad_(True), ea.double().requires_grad_(True)
+    h = torch.cat([x64[src.long()], x64[dst.long()], e64], dim=-1)
+    for i in (0, 2, 4):
+        h = torch.nn.functional.linear(h, sd[f"m.model.{i}.weight"].double(), sd[f"m.model.{i}.bias"].double())
+        h = torch.relu(h) if i < 4 else h
+    h = torch.nn.functional.layer_norm(h, (d,), sd["m.model.5.weight"].double(), sd["m.model.5.bias"].double(), 1e-5) + e64
+    h.backward(gout.double())
+    ws = [sd[f"m.model.{i}.weight"].to(DEV) for i in (0, 2, 4)]
+    bs = [sd[f"m.model.{i}.bias"].to(DEV) for i in (0, 2, 4)]
+    ln = (sd["m.model.5.weight"].to(DEV), sd["m.model.5.bias"].to(DEV), 1e-5)
+    got = []
+    for _ in range(2):
+        xd, ed = xs.to(DEV).requires_grad_(True), ea.to(DEV).requires_grad_(True)
+        y = Fn.fused_mlp([(xd, src.to(DEV)), (xd, dst.to(DEV)), (ed, None)], ws, bs, ln=ln, residual=ed)
+        y.backward(gout.to(DEV))
+        got.append((xd.grad.clone(), ed.grad.clone()))
+    assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][1], got[1][1])
+    assert max_abs(got[0][0].cpu(), x64.grad.float()) < 5e-5 * max(1.0, float(x64.grad.abs().max()))
+    assert max_abs(got[0][1].cpu(), e64.grad.float()) < 2e-5 * max(1.0, float(e64.grad.abs().max()))

@@ -437,6 +437,8 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(tmp_path):
         if "--mode" not in extra:  # N > 1: the forward step is replayed from one hipGraph (small shards are launch-bound)
             assert d["step_launch"].startswith("one hipGraph replay"), d["step_launch"]
         tr = d["train"]
+        # the training step too: forward + CE + backward + gradient pack replayed, then ONE collective and the Adam launch
+        assert tr["step_launch"].startswith("one hipGraph replay"), tr["step_launch"]
         assert tr["collectives_per_step"] == 1.0 and tr["allreduce_ms"] > 0 and tr["value"] > 0
         assert tr["allreduce_bytes"] >= 4 * 60_000
 
@@ -500,3 +502,109 @@ def test_hip_backward_odd_widths_agree_with_torch_recompute_backward(G, monkeypa
         a, b = grads[True][k], grads[False][k]
         assert float((a - b).norm() / b.norm().clamp_min(1e-12)) < 1e-3, (width, k)
         assert max_abs(a, b) < 3e-3 * max(1.0, float(b.abs().max())), (width, k)
+
+
+@pytest.mark.parametrize("out_edge,hidden", [(30, 32), (30, 64), (22, 48)])
+def test_hip_backward_edge_width_not_a_multiple_of_four(G, monkeypatch, out_edge, hidden):
+    """Edge latents whose width is not a multiple of 4 reach the kernels through a zero-padded copy, so the residual is
+    NOT the staged segment and its gradient (the effective output gradient: rows + the aggregation's gathered part) has
+    to be added by the caller: the W-split backward must then get that sum as a tensor (advisor finding, round 2)."""
+    from graphnet_classifier_amd import functional as Fn
+    from graphnet_classifier_amd import synthetic as S
+    batch = S.superpixel_like_graphs(3, seed=out_edge)
+    x, pos, ei = batch.x.to(DEV), batch.pos.to(DEV), batch.edge_index.to(DEV)
+    w = torch.randn(batch.num_nodes, 1, device=DEV)
+    torch.manual_seed(out_edge + hidden)
+    m = G.GraphNet(n_blocks=2, out_dim_node=32, out_dim_edge=out_edge, hidden_dim_node=32, hidden_dim_edge=hidden,
+                   hidden_dim_decoder=32, hidden_dim_processor_node=32, hidden_dim_processor_edge=hidden)
+    grads = {}
+    for hip in (True, False):
+        monkeypatch.setattr(Fn, "HIP_BACKWARD", hip)
+        m.zero_grad()
+        (m(x, pos, ei) * w).sum().backward()
+        grads[hip] = {k: p.grad.clone() for k, p in m.named_parameters()}
+    for k in grads[True]:
+        a, b = grads[True][k], grads[False][k]
+        assert float((a - b).norm() / b.norm().clamp_min(1e-12)) < 1e-3, (k,)
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        assert max_abs(m(x, pos, ei).cpu(), O.graphnet_forward(sd, batch.x, batch.pos, batch.edge_index)) < TOL
+
+
+def test_g9_default_model_gradients_match_reference(G):
+    """The default-width (128, 3 blocks: main.py:72-73) training step on the R = 32 pixel graph: logits, loss and all
+    76 parameter gradients against what the reference's own classes produced (golden G9).  This is the pin of the
+    128-wide K8 kernels (streamed weights, 32-row tiles, 2-wave small-batch instances) against reference gradients."""
+    g = load_golden("g9_default_train_grads.npz")
+    m = G.CombinedModel(G.GraphNet(num_local_features=3, space_dim=2, out_channels=1, n_blocks=3), num_nodes=1024, classes=2)
+    m.load_state_dict(sub_state_dict(g, "before/"), strict=True)
+    logits = m((t(g["x"]), t(g["pos"]), t(g["edge_index"])))
+    loss = torch.nn.CrossEntropyLoss()(logits, t(g["label"]))
+    m.zero_grad()
+    loss.backward()
+    assert max_abs(logits.detach(), t(g["logits"])) < TOL
+    assert abs(float(loss) - float(g["loss"])) < TOL
+    # Noise floor of this comparison: the reference's fp32 gradients differ from an fp64 run of the same model by up to
+    # 9.7e-3 of a tensor's largest entry (blocks.1 edge processor, second Linear): a pre-activation within rounding of
+    # zero takes the other ReLU branch, which moves one row's whole contribution.  The HIP path sums in another order
+    # (W-split, MFMA k-order), so it sits at the same kind of distance: entries are compared at rounding level, and the
+    # few that a flipped unit moves are bounded tensor-wise.
+    close = total = 0
+    for k, p in m.named_parameters():
+        ref = t(g["grad/" + k])
+        assert p.grad is not None, k
+        got = p.grad.cpu()
+        tol = 2e-5 + 1e-4 * float(ref.abs().max())
+        close += int(((got - ref).abs() < tol).sum())
+        total += ref.numel()
+        assert float((got - ref).norm() / ref.norm().clamp_min(1e-12)) < 2e-2, (k, float((got - ref).norm() / ref.norm()))
+        assert max_abs(got, ref) < 2e-5 + 3e-2 * float(ref.abs().max()), (k, max_abs(got, ref), float(ref.abs().max()))
+    assert close / total > 0.995, close / total
+    assert len(list(m.named_parameters())) == 76
+
+
+@pytest.mark.parametrize("name", ["c2", "c5"])
+def test_full_size_backward_against_oracle_autograd_on_sampled_graphs(G, name):
+    """BASELINE sizes, backward: `(y * w).sum().backward()` over the FULL batch (c2: 10k graphs at width 128, c5: 500k
+    nodes / 5M edges at width 256; edge tables beyond 4 GiB) with `x.requires_grad_()`.  The batch is block diagonal, so
+    the input gradient of a graph depends on that graph alone: the rows of x.grad that belong to the first, middle and
+    last graphs are checked against the oracle's CPU autograd on those graphs (the oracle's autograd is pinned by the
+    reference's own gradients in test_oracle_golden.py, goldens G5 / G9), plus bitwise run-to-run reproducibility."""
+    from graphnet_classifier_amd import synthetic as S
+    batch, kw = S.make_workload(name, 1.0)
+    torch.manual_seed(13)
+    m = G.GraphNet(**kw)
+    wgt = torch.randn(batch.num_nodes, 1, generator=torch.Generator().manual_seed(5))
+    pos, ei = batch.pos.to(DEV), batch.edge_index.to(DEV)
+    wd = wgt.to(DEV)
+    grads = []
+    for _ in range(2):
+        x = batch.x.to(DEV).requires_grad_(True)
+        m.zero_grad(set_to_none=True)
+        (m(x, pos, ei) * wd).sum().backward()
+        grads.append(x.grad.cpu())
+        del x
+    assert torch.equal(grads[0], grads[1])
+    assert batch.num_edges * kw["out_dim_edge"] * 4 > (1 << 32)
+    gx = grads[0]
+    assert bool(torch.isfinite(gx).all())
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    ng = batch.num_graphs
+    for g0 in (0, ng // 2, ng - 3):
+        s = batch.slice_graphs(g0, g0 + 3)
+        n0 = int(batch.graph_ptr[g0])
+        xs = s.x.clone().requires_grad_(True)
+        O.set_scatter_impl("index_add")  # the differentiable restatement of models/GNN.py:18-20
+        try:
+            (O.graphnet_forward(sd, xs, s.pos, s.edge_index) * wgt[n0:n0 + s.num_nodes]).sum().backward()
+        finally:
+            O.set_scatter_impl("sorted_loop")
+        ref = xs.grad
+        got = gx[n0:n0 + s.num_nodes]
+        # a pre-activation within rounding of zero may take the other ReLU branch on one side (different fp32 summation
+        # orders; the same happens between the reference's fp32 and an fp64 run of it, see the G9 test): the entries
+        # downstream of such a unit move by a visible amount while the rows as a whole agree at rounding level
+        tol = 2e-5 + 1e-4 * float(ref.abs().max())
+        assert float(((got - ref).abs() < tol).float().mean()) > 0.99, (name, g0)
+        assert float((got - ref).norm() / ref.norm().clamp_min(1e-12)) < 2e-3, (name, g0)
+        assert max_abs(got, ref) < 2e-5 + 2e-2 * float(ref.abs().max()), (name, g0)

@@ -254,3 +254,66 @@ def test_gathered_id_outside_the_table_reads_zero_in_every_kernel_variant():
         d.seg[0].table_rows = 0
         import ctypes
         native._check(native.load_library().gnc_mlp_forward_f32(ctypes.byref(d), 0), "gnc_mlp_forward_f32")
+
+
+def test_captured_step_after_eager_default_stream_training(G):
+    """The sequence that used to take the process down at hipStreamEndCapture (tools/repro_capture2.py MODE=eager_first):
+    one EAGER training step on the legacy default stream whose `loss` stays alive - so the parameters' AccumulateGrad
+    nodes, bound to the default stream, stay alive too - and then a CapturedTrainStep built directly by the caller.
+    The captured step differentiates private aliases of the parameters, so none of those nodes is reachable from the
+    capture; the replayed step must equal the same step run eagerly."""
+    from graphnet_classifier_amd.train import CapturedTrainStep, FlatParameters, FusedAdam
+    g = load_golden("g8_training_run.npz")
+    ds = _g8_dataset(g)
+    crit = torch.nn.CrossEntropyLoss()
+    finals = {}
+    for mode in ("captured", "eager"):
+        m = G.CombinedModel(G.GraphNet(**_kwargs(g)), num_nodes=64, classes=2)
+        m.load_state_dict(sub_state_dict(g, "before/"), strict=True)
+        opt = FusedAdam(FlatParameters(m))
+        loss_sum = torch.zeros((), dtype=torch.float64, device=DEV)
+        assert torch.cuda.current_stream() == torch.cuda.default_stream()
+        (s0, l0), (s1, l1) = ds
+        loss = crit(m((s0[0].to(DEV), s0[1].to(DEV), s0[2])), l0.to(DEV))  # eager, default stream; `loss` kept alive on purpose
+        opt.zero_grad(); loss.backward(); opt.step()
+        loss_sum += loss.detach().double()
+        if mode == "captured":
+            step = CapturedTrainStep(m, opt, crit, s1, l1, loss_sum)
+            step(s1, l1)
+            step(s0, l0)
+        else:
+            for s, l in ((s1, l1), (s0, l0)):
+                lo = crit(m((s[0].to(DEV), s[1].to(DEV), s[2])), l.to(DEV))
+                opt.zero_grad(); lo.backward(); opt.step()
+                loss_sum += lo.detach().double()
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(loss)) and int(opt.step_count.item()) == 3
+        finals[mode] = ({k: v.detach().cpu().clone() for k, v in m.state_dict().items()}, float(loss_sum))
+        # the module's own .grad are the flat views holding the last step's gradient, as after an eager step
+        assert all(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in zip(opt.fp.params, opt.fp.reducer.views))
+    assert finals["captured"][1] == finals["eager"][1]
+    for k in finals["eager"][0]:
+        assert torch.equal(finals["captured"][0][k], finals["eager"][0][k]), k
+
+
+def test_captured_step_restores_batchnorm_buffers(G):
+    """Constructing a CapturedTrainStep must not train: the warm-up steps' effect on BatchNorm running statistics is
+    undone like their effect on the parameters and the Adam state (advisor finding, round 2)."""
+    from graphnet_classifier_amd.train import CapturedTrainStep, FlatParameters, FusedAdam
+    g = load_golden("g8_training_run.npz")
+    kw = dict(_kwargs(g), norm_type="BatchNorm1d")
+    torch.manual_seed(0)
+    m = G.CombinedModel(G.GraphNet(**kw), num_nodes=64, classes=2)
+    m.train()
+    (s0, l0), _ = _g8_dataset(g)
+    opt = FusedAdam(FlatParameters(m))
+    before = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    loss_sum = torch.zeros((), dtype=torch.float64, device=DEV)
+    step = CapturedTrainStep(m, opt, torch.nn.CrossEntropyLoss(), s0, l0, loss_sum)
+    torch.cuda.synchronize()
+    assert any("running_mean" in k for k in before)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    step(s0, l0)
+    torch.cuda.synchronize()
+    assert any(not torch.equal(v, before[k]) for k, v in m.state_dict().items() if "running_mean" in k)

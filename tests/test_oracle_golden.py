@@ -182,3 +182,25 @@ def _g8_steps(g, sd, opt, crit, xs, pos, ei):
             opt.step()
             k += 1
     assert k == len(g["step_logits"])
+
+
+def test_g9_default_model_gradients_are_reproduced_by_the_oracle():
+    """G9 = logits, loss and all 76 parameter gradients of the reference's DEFAULT model (main.py:72-73: widths 128,
+    3 blocks) on the R = 32 pixel graph of static/muffin/img_4_880_32.jpg, captured from the reference's own classes
+    (make_golden.py::default_model_gradients).  The oracle + torch autograd on the CPU must reproduce them: that is
+    what makes the oracle's autograd a valid checker for the full-size backward tests on the GPU."""
+    g = load_golden("g9_default_train_grads.npz")
+    sd = {k: v.clone().requires_grad_(True) for k, v in sub_state_dict(g, "before/").items()}
+    O.set_scatter_impl("index_add")  # the differentiable restatement of models/GNN.py:18-20 (the edge-ordered loop detaches)
+    try:
+        logits = O.combined_forward(sd, t(g["x"]), t(g["pos"]), t(g["edge_index"]))
+    finally:
+        O.set_scatter_impl("sorted_loop")
+    assert max_abs(logits.detach(), t(g["logits"])) < TOL
+    loss = -(logits - torch.logsumexp(logits, 0))[int(g["label"])]
+    assert abs(float(loss.detach()) - float(g["loss"])) < TOL
+    loss.backward()
+    assert sum(1 for k in g if k.startswith("grad/")) == 76 == len(sd)
+    for k, v in sd.items():
+        ref = t(g["grad/" + k])
+        assert v.grad is not None and max_abs(v.grad, ref) < 2e-5 + 1e-4 * float(ref.abs().max()), k

@@ -33,10 +33,12 @@ else:
         s2 = (s[0].to("cuda:0"), s[1].to("cuda:0"), s[2])
         with torch.no_grad():
             m(s2)
-    if mode == "eager_first":
+    if mode in ("eager_first", "eager_first_del"):
         s, l = ds[0]
         s2 = (s[0].to("cuda:0"), s[1].to("cuda:0"), s[2])
         loss = crit(m(s2), l.to("cuda:0")); opt.zero_grad(); loss.backward(); opt.step(); loss_sum += loss.detach().double()
+        if mode == "eager_first_del":  # drop the old graph: its AccumulateGrad nodes (stream = legacy default) die with it
+            del loss
     c = T.CapturedTrainStep(m, opt, crit, ds[1][0], ds[1][1], loss_sum)
     c(ds[0][0], ds[0][1]); torch.cuda.synchronize()
     print("captured ok", mode, float(loss_sum), flush=True)
