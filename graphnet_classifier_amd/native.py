@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 GNC_MAX_SEGMENTS = 4
 GNC_MAX_LINEAR = 8
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 ACTIVATIONS = {  # nn.<Name> accepted by the reference's MLP(activation=...) (models/MLP.py:21)
     "ReLU": 0, "Identity": 1, "Tanh": 2, "Sigmoid": 3, "SiLU": 4, "GELU": 5, "LeakyReLU": 6, "ELU": 7,
@@ -36,6 +36,9 @@ _SIGNATURES = {
                                     c_void_p]),
     "gnc_csr_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "gnc_csr_build": (c_int32, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "gnc_topology_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int32]),
+    "gnc_topology_build": (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_size_t, c_int32, c_void_p]),
     "gnc_permute_index_i64_i32": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "gnc_permute_index_checked_i64_i32": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "gnc_scatter_sum_csr_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p,
@@ -176,10 +179,11 @@ class KernelTimers:
     object).  Events are recorded on the stream the kernel is launched on (torch's current
     stream); nothing is synchronised until ``summary()`` is called after the timed region."""
 
-    def __init__(self):
+    def __init__(self, only: str | None = None):
         self.events = {}
         self.work = {}
         self._pool = []
+        self.only = only  # time launches of this name alone (every event record is a few microseconds of GPU time)
 
     def reserve(self, launches: int) -> None:
         """Create (and record once, which is what makes the runtime allocate them) the events of ``launches``
@@ -195,6 +199,8 @@ class KernelTimers:
         return sum(len(v) for v in self.events.values())
 
     def launch(self, name: str, stream_tensor: torch.Tensor, fn, work: float = 0.0):
+        if self.only is not None and name != self.only:
+            return fn()
         start = self._pool.pop() if self._pool else torch.cuda.Event(enable_timing=True)
         end = self._pool.pop() if self._pool else torch.cuda.Event(enable_timing=True)
         start.record(torch.cuda.current_stream(stream_tensor.device))
@@ -247,6 +253,35 @@ def csr_build(index: torch.Tensor, num_nodes: int):
         _check(lib.gnc_csr_build(index.data_ptr(), e, num_nodes, rowptr.data_ptr(), perm.data_ptr(), status.data_ptr(),
                                  ws.data_ptr(), nbytes, _stream(index)), "gnc_csr_build")
     return rowptr, perm, status
+
+
+def topology_build(src: torch.Tensor | None, dst: torch.Tensor, num_nodes: int, gated_fallback: bool = True):
+    """(rowptr int32 [N+1], perm int32 [E], src_sorted int32 [E] | None, dst_sorted int32 [E] | None, status int32 [3]) of
+    one edge list in ONE call (include/gnc_hip.h, gnc_topology_build): graph-ordered batches are sorted range by range in
+    LDS; anything else raises status[2] on the device and - with ``gated_fallback`` - is sorted by the general kernels
+    enqueued behind it.  ``src`` / ``dst``: int64 or int32 [E] on the device; ``src=None`` gives rowptr and perm only."""
+    lib = load_library()
+    _require_cuda(dst, src)
+    if dst.dtype not in (torch.int64, torch.int32):
+        dst = dst.long()
+    dst = dst.contiguous()
+    if src is not None:
+        src = src.to(dst.dtype).contiguous()
+    e, dev = dst.numel(), dst.device
+    rowptr = torch.empty(num_nodes + 1, dtype=torch.int32, device=dev)
+    perm = torch.empty(e, dtype=torch.int32, device=dev)
+    ends = torch.empty(2, e, dtype=torch.int32, device=dev) if src is not None else None
+    status = torch.empty(3, dtype=torch.int32, device=dev)  # zeroed by the call
+    with torch.cuda.device(dev):
+        nbytes = lib.gnc_topology_workspace_bytes(num_nodes, e, 1 if gated_fallback else 0)
+        if nbytes == 0:
+            _check(-1, "gnc_topology_workspace_bytes")
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _check(lib.gnc_topology_build(src.data_ptr() if src is not None else None, dst.data_ptr(), dst.element_size(), e, num_nodes,
+                                      rowptr.data_ptr(), perm.data_ptr(), ends[0].data_ptr() if ends is not None else None,
+                                      ends[1].data_ptr() if ends is not None else None, status.data_ptr(), ws.data_ptr(), nbytes,
+                                      1 if gated_fallback else 0, _stream(dst)), "gnc_topology_build")
+    return rowptr, perm, (ends[0] if ends is not None else None), (ends[1] if ends is not None else None), status
 
 
 def permute_index_checked(src: torch.Tensor, perm: torch.Tensor | None, num_nodes: int, status: torch.Tensor) -> torch.Tensor:

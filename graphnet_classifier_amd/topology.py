@@ -75,27 +75,37 @@ class GraphTopology:
         self.num_edges = int(ei.size(1))
         self.device = device
         row, col = ei[0].contiguous(), ei[1].contiguous()
-        self.rowptr, self.perm, status = native.csr_build(col, self.num_nodes)
-        self.src_sorted = native.permute_index_checked(row, self.perm, self.num_nodes, status[1:])
-        self.dst_sorted = native.permute_index(col, self.perm)
+        mode = _VALIDATION if validate is True else validate
+        # ONE call (gnc_topology_build): graph-ordered batches are sorted range by range in LDS, anything else raises a
+        # device flag and takes a general path.  Deferred / unvalidated builds enqueue that general path gated on the
+        # device (no host sync, capturable); a synchronous build reads the flags back anyway and reruns through rocPRIM.
+        sync = bool(mode) and mode != "deferred"
+        self.rowptr, self.perm, self.src_sorted, self.dst_sorted, flags = native.topology_build(row, col, self.num_nodes,
+                                                                                                gated_fallback=not sync)
         self._row, self._col = row, col  # int32 copies in ORIGINAL edge order are built on first use
         self._row32 = None
         self._col32 = None
         self._inv_perm = None
         self._csc = None
-        self.status = status  # device int32 [2]: out-of-range destination / source flags
-        mode = _VALIDATION if validate is True else validate
+        self.status = flags[:2]  # device int32 [2]: out-of-range destination / source flags
         if mode == "deferred":
-            _pending.append((status, self.num_nodes))
+            _pending.append((self.status, self.num_nodes))
             # bound the list; never from inside a hipGraph capture (the read-back is a host sync)
             if len(_pending) > 4096 and not torch.cuda.is_current_stream_capturing():
                 check_deferred()
         elif mode:
             # one host sync per topology build; the reference syncs on every scatter
             # (models/GNN.py:16-17 `index.max().item()`) and raises IndexError for a bad index
-            bad_dst, bad_src = status.tolist()  # both flags, one sync
+            bad_dst, bad_src, general = flags.tolist()  # all flags, one sync
             if bad_dst or bad_src:
                 raise IndexError(f"edge_index has node ids outside [0, {self.num_nodes})")
+            if general:  # not a graph-ordered batch of small graphs: global radix sort (rocPRIM) + the two permute passes
+                self.rowptr, self.perm, status = native.csr_build(col, self.num_nodes)
+                self.src_sorted = native.permute_index_checked(row, self.perm, self.num_nodes, status[1:])
+                self.dst_sorted = native.permute_index(col, self.perm)
+                self.status = status
+                if any(status.tolist()):  # the LDS path had not looked at every source before it gave up
+                    raise IndexError(f"edge_index has node ids outside [0, {self.num_nodes})")
         self.deferred = mode == "deferred"
 
     @property
@@ -126,7 +136,8 @@ class GraphTopology:
         """(rowptr, perm) of the SOURCE-sorted order, in sorted-edge numbering: used by the
         backward of the fused gather (grad wrt x[src]) -- built on first use."""
         if self._csc is None:
-            rp, pm, _ = native.csr_build(self.src_sorted.long(), self.num_nodes)
+            # sources of a graph-ordered batch are as local as its destinations: same LDS path (int32 ids, no endpoints)
+            rp, pm, _, _, _ = native.topology_build(None, self.src_sorted, self.num_nodes, gated_fallback=True)
             self._csc = (rp, pm)
         return self._csc
 

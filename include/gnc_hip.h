@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GNC_ABI_VERSION 16
+#define GNC_ABI_VERSION 17
 
 enum {
   GNC_OK = 0,
@@ -78,6 +78,29 @@ int gnc_permute_index_i64_i32(const int64_t* src, const int32_t* perm, int64_t n
  * the flag (models/GNN.py:18-20: `index_add_` raises IndexError for such an id). */
 int gnc_permute_index_checked_i64_i32(const int64_t* src, const int32_t* perm, int64_t n, int64_t num_nodes, int32_t* out,
                                       int32_t* status, void* stream);
+
+/* ---- topology of a graph-ordered batch in one call (ABI 17) --------------------------------
+ * Everything `GraphNet.forward` needs of `edge_index` (models/GNN.py:98 `_, col = edge_index`, the x[row] / x[col]
+ * gathers of MetaLayer at :215) from ONE call: the destination CSR (rowptr, perm: the stable sort of gnc_csr_build) and
+ * both endpoint vectors narrowed to int32 and reordered by it (src_sorted[k] = src[perm[k]], dst_sorted[k] = dst[perm[k]];
+ * what gnc_permute_index_checked_i64_i32 / gnc_permute_index_i64_i32 give).  Batches of small graphs whose edges are
+ * contiguous in edge_index (the reference's loader yields one self-contained graph per item, utils/dataloader.py:33-53;
+ * graphs of at most 2048 edges) are sorted range by range in LDS without a global radix sort;
+ * any other edge list raises status[2] ON THE DEVICE and is sorted by a general stable LSD radix sort whose kernels
+ * are enqueued behind it and return at once unless the flag is set - so the call never synchronises and can be
+ * captured (gated_fallback = 1).  A caller that reads the flags back anyway may pass gated_fallback = 0 (smaller
+ * workspace) and run gnc_csr_build + the permutes itself when status[2] is set.
+ *
+ *   src, dst      [E] int64 (index_bytes = 8) or int32 (index_bytes = 4) node ids; src may be NULL: then only rowptr and
+ *                 perm are produced (src_sorted / dst_sorted ignored)
+ *   status [3]    out: [0] = a destination outside [0, N), [1] = a source outside [0, N) (such ids are replaced by 0:
+ *                 nothing downstream can index out of range; models/GNN.py:18-20 raises IndexError there),
+ *                 [2] = the LDS path could not take this edge list (informational when gated_fallback = 1)
+ */
+size_t gnc_topology_workspace_bytes(int64_t num_nodes, int64_t num_edges, int32_t gated_fallback);
+int gnc_topology_build(const void* src, const void* dst, int32_t index_bytes, int64_t num_edges, int64_t num_nodes,
+                       int32_t* rowptr, int32_t* perm, int32_t* src_sorted, int32_t* dst_sorted, int32_t* status,
+                       void* workspace, size_t workspace_bytes, int32_t gated_fallback, void* stream);
 
 /* ---- K1: scatter-sum neighbourhood aggregation ------------------------------------------
  * Replaces `scatter_sum(edge_attr, col, dim=0)` (models/GNN.py:99 -> :11-21):

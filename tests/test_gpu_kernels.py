@@ -54,6 +54,126 @@ def test_csr_build_flags_out_of_range(native):
     assert perm.cpu().tolist()[:3] == [0, 2, 5]
 
 
+# ------------------------------------------------------------------ topology in one call (gnc_topology_build)
+def _batch_of_graphs(rng, sizes, edges_per_graph, gap=0):
+    """Graph-ordered edge list: graph g owns a contiguous node range (plus `gap` isolated ids behind it), edges contiguous."""
+    src, dst, base = [], [], 0
+    for n, e in zip(sizes, edges_per_graph):
+        src.append(base + rng.integers(0, n, size=e))
+        dst.append(base + rng.integers(0, n, size=e))
+        base += n + gap
+    return np.concatenate(src).astype(np.int64), np.concatenate(dst).astype(np.int64), base
+
+
+def _topology_cases():
+    rng = np.random.default_rng(2025)
+    cases = {}
+    s, d, n = _batch_of_graphs(rng, [160] * 50, [1600] * 50)
+    cases["c3_like"] = (s, d, n, 0)
+    sizes = rng.choice([144, 156, 169], size=120)
+    s, d, n = _batch_of_graphs(rng, sizes, rng.integers(770, 913, size=120))
+    cases["c2_like_ragged"] = (s, d, n, 0)
+    s, d, n = _batch_of_graphs(rng, [40] * 9, [300] * 9, gap=500)  # isolated node ids between the graphs and behind them
+    cases["gaps_of_isolated_nodes"] = (s, d, n + 777, 0)
+    s, d, n = _batch_of_graphs(rng, [40] * 9, [300] * 9, gap=5000)  # ... so many that a range spans more than 4096 ids
+    cases["gaps_wider_than_the_span_limit"] = (s, d, n + 777, 1)
+    ei = O.grid_edge_index(32, 32)
+    cases["pixel_grid_32"] = (ei[0], ei[1], 1024, 0)
+    cases["pixel_grid_32_x7"] = (np.concatenate([ei[0] + 1024 * k for k in range(7)]), np.concatenate([ei[1] + 1024 * k for k in range(7)]), 7168, 0)
+    d = np.sort(rng.integers(0, 30000, size=200000)).astype(np.int64)
+    cases["sorted_destinations"] = (rng.integers(0, 30000, size=200000).astype(np.int64), d, 30000, 0)
+    cases["one_edge"] = (np.array([0], dtype=np.int64), np.array([0], dtype=np.int64), 1, 0)
+    cases["exactly_one_tile"] = _batch_of_graphs(rng, [100] * 2, [1024] * 2) + (0,)
+    cases["random_small"] = (rng.integers(0, 37, size=211).astype(np.int64), rng.integers(3, 37, size=211).astype(np.int64), 37, 0)
+    # ---- edge lists the LDS path must hand to the general path (status[2] == 1)
+    cases["random_large"] = (rng.integers(0, 100003, size=1000003).astype(np.int64), rng.integers(0, 100003, size=1000003).astype(np.int64), 100003, 1)
+    cases["random_medium"] = (rng.integers(0, 1000, size=12345).astype(np.int64), rng.integers(0, 1000, size=12345).astype(np.int64), 1000, 1)
+    ei = O.grid_edge_index(128, 128)
+    cases["pixel_grid_128"] = (ei[0], ei[1], 128 * 128, 1)  # one graph of 32,512 edges
+    s, d, n = _batch_of_graphs(rng, [160] * 6, [1600, 1600, 5000, 1600, 1600, 1600])
+    cases["one_big_graph_among_small"] = (s, d, n, 1)
+    s, d, n = _batch_of_graphs(rng, [160] * 5, [900] * 5)
+    d[2000:2300] = 400  # a hub: in-degree 300 inside the third graph
+    cases["hub_destination"] = (s, d, n, 0)
+    s, d, n = _batch_of_graphs(rng, [50] * 4, [2000] * 4)
+    d[:] = (d // 50) * 50 + 7  # every edge of a graph into ONE node: in-degree 2000
+    cases["star_graphs"] = (s, d, n, 0)
+    s, d, n = _batch_of_graphs(rng, [9000] * 3, [2000] * 3)  # destination span of a range above 4096
+    cases["wide_span"] = (s, d, n, 1)
+    return cases
+
+
+_TOPO = _topology_cases()
+
+
+@pytest.mark.parametrize("name", sorted(_TOPO))
+def test_topology_build_matches_stable_sort(native, name):
+    """gnc_topology_build: rowptr / perm bit-equal to a stable argsort by destination, endpoint vectors equal to
+    src[perm] / dst[perm], for graph-ordered batches (LDS path, status[2] == 0) and for edge lists that are not
+    (device-gated general path, status[2] == 1); without the gated path the flag alone must tell."""
+    src, dst, n, general = _TOPO[name]
+    order = np.argsort(dst, kind="stable")
+    ref_rowptr = np.concatenate([[0], np.cumsum(np.bincount(dst, minlength=n))]).astype(np.int32)
+    rowptr, perm, ss, ds, status = native.topology_build(torch.from_numpy(src).to(DEV), torch.from_numpy(dst).to(DEV), n, gated_fallback=True)
+    assert status.tolist() == [0, 0, general]
+    assert np.array_equal(rowptr.cpu().numpy(), ref_rowptr)
+    assert np.array_equal(perm.cpu().numpy(), order.astype(np.int32))
+    assert np.array_equal(ss.cpu().numpy(), src[order].astype(np.int32))
+    assert np.array_equal(ds.cpu().numpy(), dst[order].astype(np.int32))
+    # int32 ids, no endpoints (what the source-sorted CSR of the backward uses), twice: bitwise reproducible
+    for _ in range(2):
+        rp2, pm2, s2, d2, st2 = native.topology_build(None, torch.from_numpy(dst.astype(np.int32)).to(DEV), n, gated_fallback=True)
+        assert s2 is None and d2 is None and st2.tolist() == [0, 0, general]
+        assert torch.equal(rp2, rowptr) and torch.equal(pm2, perm)
+    # without the gated general path: the flag tells the caller to sort some other way
+    rp3, pm3, _, _, st3 = native.topology_build(torch.from_numpy(src).to(DEV), torch.from_numpy(dst).to(DEV), n, gated_fallback=False)
+    assert st3.tolist() == [0, 0, general]
+    if not general:
+        assert torch.equal(rp3, rowptr) and torch.equal(pm3, perm)
+
+
+def test_topology_build_empty_and_bad_ids(native):
+    rowptr, perm, ss, ds, status = native.topology_build(torch.zeros(0, dtype=torch.int64, device=DEV), torch.zeros(0, dtype=torch.int64, device=DEV), 7)
+    assert rowptr.tolist() == [0] * 8 and perm.numel() == 0 and status.tolist() == [0, 0, 0]
+    src = torch.tensor([3, 0, 7, 2, 1, 9], dtype=torch.int64, device=DEV)
+    dst = torch.tensor([0, 5, 2, -1, 4, 3], dtype=torch.int64, device=DEV)
+    rowptr, perm, ss, ds, status = native.topology_build(src, dst, 8)
+    assert status.tolist()[:2] == [1, 1]
+    # ids are sanitised: nothing downstream can index out of range before the host has raised
+    assert int(ss.min()) >= 0 and int(ss.max()) < 8 and int(ds.min()) >= 0 and int(ds.max()) < 8
+    assert int(rowptr.min()) >= 0 and int(rowptr.max()) <= 6 and sorted(perm.tolist()) == list(range(6))
+    # the module API turns the flags into the reference's IndexError (models/GNN.py:18-20)
+    from graphnet_classifier_amd.topology import GraphTopology
+    with pytest.raises(IndexError):
+        GraphTopology(torch.stack([src, dst.clamp(0, 7)]), 8, device=DEV)
+    with pytest.raises(IndexError):
+        GraphTopology(torch.stack([src.clamp(0, 7), dst]), 8, device=DEV)
+
+
+def test_graph_topology_takes_the_general_path_for_edge_lists_that_are_not_graph_ordered(native):
+    """Module level: a synchronous build of a random edge list reruns through rocPRIM, a deferred one through the gated
+    kernels; both equal the stable sort, and so does the source-sorted CSR of the backward."""
+    from graphnet_classifier_amd import topology
+    rng = np.random.default_rng(5)
+    n, e = 3000, 50000
+    ei = torch.from_numpy(rng.integers(0, n, size=(2, e)).astype(np.int64))
+    order = np.argsort(ei[1].numpy(), kind="stable")
+    topos = [topology.GraphTopology(ei, n, device=DEV)]
+    topology.set_validation("deferred")
+    try:
+        topos.append(topology.GraphTopology(ei, n, device=DEV))
+        topology.check_deferred()
+    finally:
+        topology.set_validation("sync")
+    for tp in topos:
+        assert np.array_equal(tp.perm.cpu().numpy(), order.astype(np.int32))
+        assert np.array_equal(tp.src_sorted.cpu().numpy(), ei[0].numpy()[order].astype(np.int32))
+        assert np.array_equal(tp.dst_sorted.cpu().numpy(), ei[1].numpy()[order].astype(np.int32))
+        rp, pm = tp.csc
+        so = np.argsort(ei[0].numpy()[order], kind="stable")
+        assert np.array_equal(pm.cpu().numpy(), so.astype(np.int32))
+
+
 # ------------------------------------------------------------------ K1 scatter-sum
 def test_permute_index_checked_flags_and_sanitises(native):
     src = torch.tensor([3, 0, 7, -1, 2, 9], dtype=torch.int64, device=DEV)
