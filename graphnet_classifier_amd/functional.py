@@ -23,6 +23,14 @@ from . import native
 HIP_BACKWARD = os.environ.get("GNC_TORCH_BACKWARD") is None
 
 
+def _node_projections(x, w0, dn):
+    """(x Ws^T, x Wd^T) [N, H] each: the per-node halves of the W-split first Linear (models/GNN.py:58-61).  Two launches:
+    one launch over the stacked weight [Ws ; Wd] (x read once, [N, 2H] written, the halves as gather tables) measured no
+    faster on the same box (c3 8.14 / 8.29 vs 8.13 / 8.25 ms per step, c2 41.51 vs 41.55) and was dropped."""
+    return (native.mlp_forward([(x, None)], [w0[:, :dn]], [None]),
+            native.mlp_forward([(x, None)], [w0[:, dn:2 * dn]], [None]))
+
+
 class _ScatterSumCSR(torch.autograd.Function):
     @staticmethod
     def forward(ctx, src, rowptr, perm, dst_of_row, num_nodes):
@@ -226,8 +234,7 @@ class _EdgeProcessorWSplit(torch.autograd.Function):
         ln = (params[2 * num_linear], params[2 * num_linear + 1], ln_eps) if has_ln else None
         dn = x.size(1)
         w0 = weights[0]
-        ps = native.mlp_forward([(x, None)], [w0[:, :dn]], [None])           # [N, H] = x Ws^T
-        pd = native.mlp_forward([(x, None)], [w0[:, dn:2 * dn]], [None])     # [N, H] = x Wd^T
+        ps, pd = _node_projections(x, w0, dn)                                 # [N, H] = x Ws^T, x Wd^T
         training = len(meta) > 8 and meta[8] and any(ctx.needs_input_grad) and HIP_BACKWARD
         acts = [] if training else None   # the hidden layers' post-activations, kept for K8 where the kernel can
         out = native.mlp_forward([(ps, src), (pd, dst), (e, None)], [w0[:, 2 * dn:]] + weights[1:], biases, ln=ln,
@@ -311,8 +318,7 @@ def _edge_wsplit_backward_hip(ctx, grad_out, grad_agg=None):
     if extra:
         ps, pd = extra[0], extra[1]
     else:
-        ps = native.mlp_forward([(x, None)], [ws_], [None])
-        pd = native.mlp_forward([(x, None)], [wd_], [None])
+        ps, pd = _node_projections(x, w0, dn)
     segments = [(ps, src), (pd, dst), (e, None)]
     modes = [native.SEG_ADD, native.SEG_ADD, native.SEG_MATMUL]
     wl = [we_] + weights[1:]
@@ -367,8 +373,7 @@ def edge_processor_wsplit_aggregated(x, e, topo, weights, biases, ln, activation
     runs K1).  ``agg`` is bit-identical to ``scatter_sum_csr(e', topo.rowptr)``."""
     dn = x.size(1)
     w0 = weights[0]
-    ps = native.mlp_forward([(x, None)], [w0[:, :dn]], [None])
-    pd = native.mlp_forward([(x, None)], [w0[:, dn:2 * dn]], [None])
+    ps, pd = _node_projections(x, w0, dn)
     return native.mlp_forward([(ps, topo.src_sorted), (pd, topo.dst_sorted), (e, None)], [w0[:, 2 * dn:]] + list(weights[1:]),
                               list(biases), ln=ln, activation=activation, act_param=act_param, residual=e, rows=e.size(0),
                               modes=[native.SEG_ADD, native.SEG_ADD, native.SEG_MATMUL],
