@@ -24,6 +24,26 @@
 #include "mlp_backward_fused.h"
 
 
+// Phase probe of the streamed kernel (developer build: make probe_b32, tools/profile_bwd16.py <iters> 128): cycles per
+// phase of the tile loop, per wave.
+#if defined(GNC_PHASE_PROBE) && !defined(GNC_BWD_PROBE_SYMBOL)
+__device__ unsigned long long gnc_phase_probe_b32[4096 * 12];
+extern "C" int gnc_phase_probe_b32_read(void* dst, size_t bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(gnc_phase_probe_b32), bytes); }
+#define B32P_BEGIN() unsigned long long pr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pr_tp, pr_tn; \
+  const unsigned long long pr_c0 = __builtin_readcyclecounter(), pr_w0 = wall_clock64()
+#define B32P_TILE() pr_tp = __builtin_readcyclecounter()
+#define B32P(k) do { pr_tn = __builtin_readcyclecounter(); pr_acc[k] += pr_tn - pr_tp; pr_tp = pr_tn; } while (0)
+#define B32P_END() do { if ((threadIdx.x & 63) == 0) {                                                          \
+    unsigned long long* o = gnc_phase_probe_b32 + (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 12;  \
+    for (int k = 0; k < 8; ++k) o[k] = pr_acc[k];                                                               \
+    o[8] = __builtin_readcyclecounter() - pr_c0; o[9] = wall_clock64() - pr_w0; } } while (0)
+#else
+#define B32P_BEGIN() do {} while (0)
+#define B32P_TILE() do {} while (0)
+#define B32P(k) do {} while (0)
+#define B32P_END() do {} while (0)
+#endif
+
 namespace {
 
 constexpr int BWAVES = 8;
@@ -456,7 +476,9 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_backward_stream_kernel(const g
   };
   auto cur_chunk = [&]() -> const float* { return wbuf + (gq & 1) * CH; };
 
+  B32P_BEGIN();
   for (int tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
+    B32P_TILE();
     const int row0 = (tile * WAVES + wave) * RPW;
 
     unsigned mask[GNC_MAX_LINEAR - 1][NCH];  // ReLU masks: 32 bits per 64-column chunk and layer
@@ -582,6 +604,7 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_backward_stream_kernel(const g
       }
     }
     }  // forward recompute
+    B32P(0);  // saved tiles -> masks (or the forward recompute)
 
     // ------------------------------------------------------------------ LayerNorm recompute FIRST (the last hidden
     // activations die with it), THEN the grad_out tile: never more than two accumulator sets live
@@ -597,6 +620,7 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_backward_stream_kernel(const g
         }
       }
     }
+    B32P(1);  // last Linear (LayerNorm statistics)
     f32x16 g[HT];
 #pragma unroll
     for (int cc = 0; cc < NCH; ++cc) {
@@ -627,6 +651,7 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_backward_stream_kernel(const g
             for (int r = 0; r < 16; ++r) g[2 * cc + tt < HT ? 2 * cc + tt : 0][r] = 0.f;
       }
     }
+    B32P(2);  // grad_out slabs
     if (d.ln_gamma) {
       layer_norm_backward_tiles<HT>(y, g, pbuf + L * PSTRIDE, out_dim, d.ln_eps, h);
       if (b.ln_partial) {
@@ -677,7 +702,9 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_backward_stream_kernel(const g
 #pragma unroll
         for (int r = 0; r < 16; ++r) g[t][r] = (feat_of(t, r, h) < out_dim) ? g[t][r] : 0.f;
     }
+    B32P(3);  // LayerNorm backward + parameter sums
     emit(g, b.dz[L - 1], out_dim, out_dim, row0);
+    B32P(4);  // emit dz_{L-1}
 
     // ------------------------------------------------------------------ back through the Linear layers
 #pragma unroll
@@ -696,6 +723,7 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_backward_stream_kernel(const g
         emit(g, b.dz[l], d.out_dim[l], d.out_dim[l], row0);
       }
     }
+    B32P(5);  // transposed products + masks + emits
     if (b.dx) {  // one 64-column slab of dx per MATMUL step, in step order (= the order of the plan's last chunks)
       for (int st = 0; st < pl.num_steps; ++st) {
         if (pl.step[st].add) continue;
@@ -719,7 +747,9 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_backward_stream_kernel(const g
         }
       }
     }
+    B32P(6);  // dx
   }
+  B32P_END();
   if (b.ln_partial) {  // one row of partials per wave: [d beta (out_dim) | d gamma (out_dim)]
     compiler_lds_barrier();
     float* dst = b.ln_partial + (int64_t)((int)blockIdx.x * WAVES + wave) * 2 * out_dim;

@@ -62,14 +62,16 @@ flops = 2.0 * e * 4 * d * d  # LayerNorm recompute + two transposed products + d
 print(f"width {d} rows {e}: saved_act {r['saved_act_used']} ms_per_launch {ms:.3f} -> {flops / ms / 1e9:.1f} TFLOP/s executed "
       f"({flops / ms / 1e9 / 157.3:.3f} of the fp32 MFMA peak)")
 lib = native.load_library()
-if hasattr(lib, "gnc_phase_probe_b16_read"):
+reader = "gnc_phase_probe_b16_read" if d > 128 else "gnc_phase_probe_b32_read"
+if hasattr(lib, reader):
     waves = 256 * 8
     buf = np.zeros(4096 * 12, dtype=np.uint64)
-    lib.gnc_phase_probe_b16_read.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
-    lib.gnc_phase_probe_b16_read(buf.ctypes.data, buf.nbytes)
+    getattr(lib, reader).argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    getattr(lib, reader)(buf.ctypes.data, buf.nbytes)
     b = buf.reshape(4096, 12)[:waves].astype(np.float64)
-    tiles = (e + 15) // 16 / waves
-    names = ["saved tiles -> masks", "grad_out slabs", "last Linear (LN stats)", "LN backward + sums", "emit dz_last", "W^T products + masks + emits", "dx", "-"]
-    print("cycles per 16-row tile and wave:", {k: round(v / tiles) for k, v in zip(names, b[:, :8].mean(0))}, "total", round(b[:, 8].mean() / tiles),
+    tiles = (e + (15 if d > 128 else 31)) // (16 if d > 128 else 32) / waves
+    names = (["saved tiles -> masks", "grad_out slabs", "last Linear (LN stats)", "LN backward + sums", "emit dz_last", "W^T products + masks + emits", "dx", "-"]
+             if d > 128 else ["saved tiles -> masks", "last Linear (LN stats)", "grad_out slabs", "LN backward + sums", "emit dz_last", "W^T products + masks + emits", "dx", "-"])
+    print("cycles per tile and wave:", {k: round(v / tiles) for k, v in zip(names, b[:, :8].mean(0))}, "total", round(b[:, 8].mean() / tiles),
           "(MFMA alone: 4096 x 32 = 131072 per tile and wave pair -> 2 waves per SIMD)")
     print("shader clock GHz during the kernel:", round(float((b[:, 8] / b[:, 9]).mean()) * 0.1, 3))
