@@ -79,7 +79,10 @@ class EdgeProcessor(nn.Module):
         mlp = self.edge_processor
         norm = mlp.model[-1] if mlp.norm_type is not None else None
         lin = mlp._linears()
-        if (WSPLIT and not isinstance(norm, nn.BatchNorm1d) and mlp.activation_name in native.ACTIVATIONS
+        # (with autograd on, only for ReLU: its backward is the fused K8 launch over the split form; another activation
+        # trains through the concat form, whose backward runs layer by layer - functional._layerwise_mlp_backward_hip)
+        trainable_split = mlp.activation_name == "ReLU" or not torch.is_grad_enabled()
+        if (WSPLIT and trainable_split and not isinstance(norm, nn.BatchNorm1d) and mlp.activation_name in native.ACTIVATIONS
                 and lin[0].in_features == 2 * x.size(1) + edge_attr.size(1) and x.size(1) % 4 == 0):
             # W-split of the first Linear: node-side products once per node, gathered and added per edge
             ln = (norm.weight, norm.bias, norm.eps) if isinstance(norm, nn.LayerNorm) else None

@@ -116,9 +116,14 @@ class _FusedMLP(torch.autograd.Function):
         acts = list(saved[len(saved) - ctx.n_acts:]) if ctx.n_acts else None
         s, l = len(meta.indices), meta.num_linear
         need = ctx.needs_input_grad[1:]
-        hip = _fused_mlp_backward_hip(meta, args, need, grad_out, acts) if HIP_BACKWARD else None
-        if hip is not None:
+        if meta.rows == 0:  # no rows: every gradient is a zero of its argument's shape (an edge-less graph, superpixel.py:70-71)
+            return (None,) + tuple(torch.zeros_like(a) if n else None for a, n in zip(args, need))
+        if HIP_BACKWARD:
+            hip = _fused_mlp_backward_hip(meta, args, need, grad_out, acts)
+            if hip is None:  # an activation other than ReLU (or a shape outside K8): layer by layer, still on this library
+                hip = _layerwise_mlp_backward_hip(meta, args, need, grad_out)
             return (None,) + hip
+        # GNC_TORCH_BACKWARD=1 (A/B and parity runs only): PyTorch-ROCm recompute backward of the same ops on the GPU
         leaves = [a.detach().requires_grad_(bool(n)) for a, n in zip(args, need)]
         tables, weights, biases = leaves[:s], leaves[s:s + l], leaves[s + l:s + 2 * l]
         rest = leaves[s + 2 * l:]
@@ -202,6 +207,75 @@ def _fused_mlp_backward_hip(meta: _MlpMeta, args, need, grad_out, saved_act=None
     return tuple(grads)
 
 
+def _layerwise_mlp_backward_hip(meta: _MlpMeta, args, need, grad_out):
+    """Backward of one fused-MLP call for the shapes the K8 kernels do not take - an activation other than ReLU
+    (models/MLP.py:21 accepts any nn.<Name>) - layer by layer on the library's own kernels: the pre-activations are
+    recomputed with single-Linear K4 launches, act / act' / the LayerNorm backward are row-wise kernels
+    (csrc/elementwise.hip), da = dz W is a single-Linear launch on the transposed weight, dW = dz^T a and db come from
+    gnc_xty_f32, gathered segments get their gradient through K1.  Nothing here is on the path of a ReLU model."""
+    s, l = len(meta.indices), meta.num_linear
+    tables, weights, biases = list(args[:s]), list(args[s:s + l]), list(args[s + l:s + 2 * l])
+    rest = list(args[s + 2 * l:])
+    act, ap = meta.activation, meta.act_param
+    if act not in native.ACTIVATIONS or not grad_out.is_cuda:
+        raise NotImplementedError(f"backward of an MLP with activation nn.{act} has no HIP kernel")
+    segments = list(zip(tables, meta.indices))
+    grad_out = grad_out.contiguous()
+    # forward recompute: z_k (pre-activations) and a_k = act(z_k)
+    zs, acts = [], []
+    z = native.mlp_forward(segments, [weights[0]], [biases[0]], activation="Identity", rows=meta.rows)
+    for k in range(l):
+        zs.append(z)
+        if k + 1 < l:
+            a = native.activation(z, act, ap)
+            acts.append(a)
+            z = native.mlp_forward([(a, None)], [weights[k + 1]], [biases[k + 1]], activation="Identity")
+    grads = [None] * len(args)
+    pos = s + 2 * l
+    if meta.has_ln:
+        dz, yhat = native.layer_norm_backward(zs[-1], rest[0], grad_out, meta.ln_eps)
+        if need[pos] or need[pos + 1]:
+            dbeta, dgamma = native.colsum_pair(grad_out, yhat)
+            grads[pos] = dgamma if need[pos] else None
+            grads[pos + 1] = dbeta if need[pos + 1] else None
+        pos += 2
+    else:
+        dz = grad_out
+    if meta.has_residual and need[pos]:
+        grads[pos] = grad_out
+    for k in range(l - 1, -1, -1):
+        want_w = need[s + k] or need[s + l + k]
+        if k > 0:
+            if want_w:
+                dw, db = native.xty(dz, acts[k - 1])
+                grads[s + k] = dw if need[s + k] else None
+                grads[s + l + k] = db if need[s + l + k] else None
+            da = native.mlp_forward([(dz, None)], [weights[k].t().contiguous()], [None], activation="Identity")  # dz W_k
+            dz = native.activation_backward(zs[k - 1], da, act, ap)
+            continue
+        # first Linear: its input is the virtual concat of the segments (gathered ones materialised for the products)
+        off, parts, db0 = 0, [], None
+        for q, (t, idx) in enumerate(segments):
+            w = t.size(1)
+            if want_w:
+                c, cs = native.xty(dz, t if idx is None else native.gather_rows(t, idx))
+                parts.append(c)
+                db0 = cs if db0 is None else db0
+            if need[q]:
+                gq = native.mlp_forward([(dz, None)], [weights[0][:, off:off + w].t().contiguous()], [None], activation="Identity")
+                if idx is None:
+                    grads[q] = gq
+                else:
+                    from .topology import get_destination_csr
+                    csr = get_destination_csr(idx, t.size(0), t.device)
+                    grads[q] = native.scatter_sum_csr(gq, csr.rowptr, csr.perm, t.size(0))
+            off += w
+        if want_w:
+            grads[s] = (torch.cat(parts, dim=1) if len(parts) > 1 else parts[0]) if need[s] else None
+            grads[s + l] = db0 if need[s + l] else None
+    return tuple(grads)
+
+
 def fused_mlp(segments, weights, biases, ln=None, activation: str = "ReLU", act_param: float = 0.0, residual=None,
               rows: int | None = None) -> torch.Tensor:
     """segments: list of (table fp32 [*, w], index int32 [rows] | None); see native.mlp_forward."""
@@ -265,11 +339,17 @@ class _EdgeProcessorWSplit(torch.autograd.Function):
             grad_agg = None
         if grad_out is None and grad_agg is None:
             return (None, None) + tuple(None for _ in need)
+        if ctx.saved_tensors[1].size(0) == 0:  # an edge-less graph (superpixel.py:70-71): zeros of every argument's shape
+            saved0 = ctx.saved_tensors[:len(ctx.saved_tensors) - getattr(ctx, "n_extra", 0)]
+            return (None, None) + tuple(torch.zeros_like(a) if n else None for a, n in zip(saved0, need))
         # e' feeds the aggregation (its backward is a row gather by destination: grad_agg[dst]) AND whatever consumed e'
         # itself (grad_out): the K8 launch adds the gathered rows itself where its kernel can
-        hip = _edge_wsplit_backward_hip(ctx, grad_out, grad_agg) if HIP_BACKWARD else None
-        if hip is not None:
+        if HIP_BACKWARD:
+            hip = _edge_wsplit_backward_hip(ctx, grad_out, grad_agg)
+            if hip is None:  # (EdgeProcessor.forward_sorted only takes the W-split route for shapes K8 serves)
+                raise NotImplementedError("W-split edge processor: this shape has no HIP backward kernel (use the concat form)")
             return (None, None) + hip
+        # GNC_TORCH_BACKWARD=1 (A/B and parity runs only): PyTorch-ROCm recompute backward of the same ops on the GPU
         if grad_agg is not None and grad_out is not None:
             grad_out = native.gather_rows_add(grad_agg.contiguous(), dst, grad_out.contiguous())
         elif grad_agg is not None:

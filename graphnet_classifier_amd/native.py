@@ -70,6 +70,11 @@ _SIGNATURES = {
                                 c_void_p, c_size_t, c_void_p]),
     "gnc_colsum_pair_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_int32, c_void_p]),
     "gnc_reduce_partials_f32": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_void_p]),
+    "gnc_activation_f32": (c_int32, [c_void_p, c_int64, c_int64, c_int32, c_int32, c_float, c_void_p, c_int64, c_void_p]),
+    "gnc_activation_backward_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, c_float, c_void_p, c_int64,
+                                              c_void_p]),
+    "gnc_layer_norm_backward_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_float, c_void_p, c_int64,
+                                              c_void_p, c_int64, c_void_p]),
     "gnc_adam_step_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float,
                                     c_void_p, c_void_p, c_void_p]),
 }
@@ -727,6 +732,46 @@ def colsum_pair(g: torch.Tensor, y: torch.Tensor):
             _check(lib.gnc_reduce_partials_f32(part.data_ptr(), p, 2 * w, 2, w, both[:, c0:c0 + w].data_ptr(), width, None,
                                                _stream(g)), "gnc_reduce_partials_f32")
     return both[0], both[1]
+
+
+# --------------------------------------------------------------------------- activations other than ReLU: backward pieces
+def activation(z: torch.Tensor, name: str, param: float = 0.0) -> torch.Tensor:
+    """act(z) elementwise (gnc_activation_f32)."""
+    lib = load_library()
+    _require_cuda(z)
+    z = _rowmajor(z)
+    out = torch.empty(z.size(0), z.size(1), dtype=torch.float32, device=z.device)
+    with torch.cuda.device(z.device):
+        _check(lib.gnc_activation_f32(z.data_ptr(), _ld(z), z.size(0), z.size(1), ACTIVATIONS[name], param, out.data_ptr(), _ld(out),
+                                      _stream(z)), "gnc_activation_f32")
+    return out
+
+
+def activation_backward(z: torch.Tensor, grad_act: torch.Tensor, name: str, param: float = 0.0) -> torch.Tensor:
+    """grad_act * act'(z) (gnc_activation_backward_f32)."""
+    lib = load_library()
+    _require_cuda(z, grad_act)
+    z, grad_act = _rowmajor(z), _rowmajor(grad_act)
+    out = torch.empty(z.size(0), z.size(1), dtype=torch.float32, device=z.device)
+    with torch.cuda.device(z.device):
+        _check(lib.gnc_activation_backward_f32(z.data_ptr(), _ld(z), grad_act.data_ptr(), _ld(grad_act), z.size(0), z.size(1),
+                                               ACTIVATIONS[name], param, out.data_ptr(), _ld(out), _stream(z)),
+               "gnc_activation_backward_f32")
+    return out
+
+
+def layer_norm_backward(y: torch.Tensor, gamma: torch.Tensor, grad_out: torch.Tensor, eps: float):
+    """(grad_y, y_hat) of out = LayerNorm(y) * gamma + beta (gnc_layer_norm_backward_f32)."""
+    lib = load_library()
+    _require_cuda(y, gamma, grad_out)
+    y, grad_out = _rowmajor(y), _rowmajor(grad_out)
+    gy = torch.empty(y.size(0), y.size(1), dtype=torch.float32, device=y.device)
+    yhat = torch.empty_like(gy)
+    with torch.cuda.device(y.device):
+        _check(lib.gnc_layer_norm_backward_f32(y.data_ptr(), _ld(y), gamma.contiguous().data_ptr(), grad_out.data_ptr(), _ld(grad_out),
+                                               y.size(0), y.size(1), eps, gy.data_ptr(), _ld(gy), yhat.data_ptr(), _ld(yhat),
+                                               _stream(y)), "gnc_layer_norm_backward_f32")
+    return gy, yhat
 
 
 # --------------------------------------------------------------------------- fused Adam

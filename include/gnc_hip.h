@@ -337,6 +337,25 @@ int gnc_colsum_pair_f32(const float* G, int64_t ldg, const float* Y, int64_t ldy
 int gnc_reduce_partials_f32(const float* partial, int32_t num_partials, int32_t stride, int32_t M, int32_t K,
                             float* dW, int64_t ld_dw, float* db, void* stream);
 
+/* ---- backward of an MLP with an activation other than ReLU (ABI 17) ---------------------------------------
+ * models/MLP.py:21 accepts any nn.<Name>; the reference's entry points only use ReLU, which the fused K8 kernels
+ * above serve.  For the other activations of GNC_ACT_* the backward runs LAYER BY LAYER on this library: the
+ * pre-activations are recomputed with single-Linear gnc_mlp_forward_f32 launches, these three row-wise / elementwise
+ * kernels provide act, act' and the LayerNorm backward, the products da = dz W are single-Linear launches on the
+ * transposed weights and the weight gradients come from gnc_xty_f32 / gnc_colsum_pair_f32.
+ *   gnc_activation_f32           out = act(z)
+ *   gnc_activation_backward_f32  grad_z = grad_act * act'(z)      (the derivative torch.autograd uses for nn.<Name>)
+ *   gnc_layer_norm_backward_f32  for out = LayerNorm(y) * gamma + beta: grad_y and the normalised y_hat of every row
+ *                                (d gamma = colsum(grad_out * y_hat), d beta = colsum(grad_out))
+ */
+int gnc_activation_f32(const float* z, int64_t ld_z, int64_t rows, int32_t width, int32_t activation, float act_param,
+                       float* out, int64_t ld_out, void* stream);
+int gnc_activation_backward_f32(const float* z, int64_t ld_z, const float* grad_act, int64_t ld_grad, int64_t rows,
+                                int32_t width, int32_t activation, float act_param, float* grad_z, int64_t ld_out, void* stream);
+int gnc_layer_norm_backward_f32(const float* y, int64_t ld_y, const float* gamma, const float* grad_out, int64_t ld_grad,
+                                int64_t rows, int32_t width, float eps, float* grad_y, int64_t ld_gy, float* yhat,
+                                int64_t ld_yhat, void* stream);
+
 /* ---- graph construction on the device ---------------------------
  * Inputs: an already resized uint8 RGB image [H, W, C] in HBM.  Outputs: the tensors
  * utils/dataloader.py:49-51 builds (x, pos float32; edge_index int64 [2, E] row-major), in the

@@ -613,3 +613,32 @@ def test_full_size_backward_against_oracle_autograd_on_sampled_graphs(G, name):
             a, b = int(s.graph_ptr[k]), int(s.graph_ptr[k + 1])
             tight.append(bool(((got[a:b] - ref[a:b]).abs() < tol).all()))
     assert sum(tight) >= 6, tight  # 9 sampled graphs
+
+
+@pytest.mark.parametrize("act", ["Tanh", "SiLU", "GELU", "LeakyReLU", "ELU", "Sigmoid"])
+def test_training_with_another_activation_runs_on_the_library_and_matches_autograd(G, monkeypatch, act):
+    """models/MLP.py:21 accepts any nn.<Name>.  For an activation other than ReLU the backward runs layer by layer on the
+    library's own kernels (functional._layerwise_mlp_backward_hip: single-Linear K4 launches, csrc/elementwise.hip, xty):
+    parameter and input gradients against the PyTorch-ROCm recompute backward of the same ops, and no silent switch to it."""
+    from graphnet_classifier_amd import functional as Fn
+    from graphnet_classifier_amd import synthetic as S
+    batch = S.superpixel_like_graphs(3, seed=9)
+    pos, ei = batch.pos.to(DEV), batch.edge_index.to(DEV)
+    w = torch.randn(batch.num_nodes, 1, device=DEV)
+    torch.manual_seed(4)
+    m = G.GraphNet(n_blocks=2, out_dim_node=32, out_dim_edge=32, hidden_dim_node=32, hidden_dim_edge=32, hidden_dim_decoder=32,
+                   hidden_dim_processor_node=32, hidden_dim_processor_edge=32, activation=act)
+    calls = []
+    real = Fn._layerwise_mlp_backward_hip
+    monkeypatch.setattr(Fn, "_layerwise_mlp_backward_hip", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    grads = {}
+    for hip in (True, False):
+        monkeypatch.setattr(Fn, "HIP_BACKWARD", hip)
+        x = batch.x.to(DEV).requires_grad_(True)
+        m.zero_grad()
+        (m(x, pos, ei) * w).sum().backward()
+        grads[hip] = dict({k: p.grad.clone() for k, p in m.named_parameters()}, x=x.grad.clone())
+    assert len(calls) >= 6  # both encoders and the two blocks' processors (the decoder keeps ReLU: models/GNN.py:289-295)
+    for k in grads[True]:
+        a, b = grads[True][k], grads[False][k]
+        assert max_abs(a, b) < 2e-5 + 1e-4 * float(b.abs().max()), (k, max_abs(a, b), float(b.abs().max()))
