@@ -290,6 +290,16 @@ extern "C" int gnc_mlp_agg_supported(const gnc_mlp_desc_t* desc) {
 }
 
 // shape-only answer for the training forward's saved post-activations: the weights-resident kernel writes them
+namespace {
+// Small batches at 65..128 features (one ~1000-node graph per call, main.py:60): a 32-row wave tile is 768 dependent
+// v_mfma_f32_32x32x2 steps (49 k cycles, 20 us) whatever the batch; 16-row tiles on v_mfma_f32_16x16x4 in 2-wave
+// workgroups halve that chain and spread the rows over twice as many SIMDs.  GNC_NO_SMALL16=1 switches back for A/B runs.
+bool small16(const gnc_mlp_desc_t& d, int T) {
+  static const bool off = getenv("GNC_NO_SMALL16") != nullptr;
+  return !off && T == 4 && d.rows <= (int64_t)2 * 16 * gnc::num_cu();
+}
+}  // namespace
+
 extern "C" int gnc_mlp_save_act_supported(const gnc_mlp_desc_t* desc) {
   int rc = validate_desc(desc, false);
   if (rc) return rc;
@@ -307,7 +317,7 @@ extern "C" int gnc_mlp_save_act_supported(const gnc_mlp_desc_t* desc) {
     rc = launch_resident(probe, T, narrow_out, nullptr, &ok, true);
     if (rc) return rc;
     static const bool s16_128 = getenv("GNC_STREAM16_D128") != nullptr;
-    if (!ok && (T == 8 || (T == 4 && s16_128 && !probe.agg_out))) {
+    if (!ok && (T == 8 || (T == 4 && s16_128 && !probe.agg_out) || small16(probe, T))) {
       rc = launch_stream16(probe, nullptr, &ok, true);
       if (rc) return rc;
     }
@@ -344,7 +354,8 @@ extern "C" int gnc_mlp_forward_f32(const gnc_mlp_desc_t* desc, void* stream_) {
     return GNC_ERR_UNSUPPORTED;
   }
   static const bool s16_128 = getenv("GNC_STREAM16_D128") != nullptr;  // A/B: 16-row kernel also for 65..128 features
-  if (T == 8 || (T == 4 && s16_128 && !desc->agg_out)) {  // 129..256 features: 16-row tiles on the 16x16x4 MFMA
+  // 129..256 features: 16-row tiles on the 16x16x4 MFMA; 65..128 features: its 2-wave instances for small batches (small16)
+  if (T == 8 || (T == 4 && s16_128 && !desc->agg_out) || small16(*desc, T)) {
     rc = launch_stream16(*desc, stream, &launched);
     if (rc || launched) return rc;
     if (desc->agg_out && T == 8) {

@@ -36,14 +36,17 @@ struct Plan16 {
 // output columns; the workgroup still steps through the weight chunks in lockstep, so waves whose range is one tile
 // shorter run a last iteration on a tile past the table's end (loads return zeros / clamped rows, stores are dropped).
 // SAVE: training forward (gnc_mlp_desc_t.save_act): the hidden layers' post-activations are also written
-template <int NTH, int NTO, bool DBUF, bool AGG = false, bool SAVE = false>
-__global__ __launch_bounds__(NT16) void mlp_stream16_kernel(const gnc_mlp_desc_t d, const Plan16 pl, const int num_tiles) {
+// WV: waves per workgroup (8; 2 for small batches: one wave per SIMD on a quarter of the rows per workgroup, four times as many
+// CUs busy - the reference's one-graph-per-call regime is MFMA-LATENCY bound: a wave's 768 dependent 16x16x4 steps per row tile)
+template <int NTH, int NTO, bool DBUF, bool AGG = false, bool SAVE = false, int WV = W16>
+__global__ __launch_bounds__(WV * 64) void mlp_stream16_kernel(const gnc_mlp_desc_t d, const Plan16 pl, const int num_tiles) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int NTW = NTH > NTO ? NTH : NTO;
   constexpr int WROWS = NTW * 16;             // weight rows per chunk buffer
   constexpr int CH = WROWS * LDSW;
   constexpr int PSTRIDE = WROWS;
-  constexpr int RPP = NT16 / 16;              // weight rows staged per pass (32)
+  constexpr int NTV = WV * 64;
+  constexpr int RPP = NTV / 16;              // weight rows staged per pass (32)
   constexpr int NW = WROWS / RPP;
   constexpr int NCHI = (NTH + 3) / 4;         // 64-column chunks of a hidden-width input
   constexpr int NCHO = (NTO + 3) / 4;
@@ -60,7 +63,7 @@ __global__ __launch_bounds__(NT16) void mlp_stream16_kernel(const gnc_mlp_desc_t
   int gq = 0;
   float* abuf = pbuf + (L + 2) * PSTRIDE + wave * R16 * LDSW;
 
-  stage_params<NT16>(pbuf, d, PSTRIDE, tid);
+  stage_params<NTV>(pbuf, d, PSTRIDE, tid);
 
   auto wload = [&](f32x4 (&wr)[NW], int q) {
     const int ftid = wave * 64 + fresh_lane();  // roles recomputed per use: nothing lane-derived is carried across the loop
@@ -104,19 +107,19 @@ __global__ __launch_bounds__(NT16) void mlp_stream16_kernel(const gnc_mlp_desc_t
   // wave tile t * 8 + wave.  AGG: one contiguous range per wave.  `iters` is workgroup-uniform.
   const int num_wtiles = (rows + R16 - 1) / R16;
   const int last_wt = num_wtiles - 1;
-  const int gwave = (int)blockIdx.x * W16 + wave;
+  const int gwave = (int)blockIdx.x * WV + wave;
   int agg_t0 = 0, agg_cnt = 0, iters;
   if constexpr (AGG) {
-    const int tw = (int)gridDim.x * W16, qq = num_wtiles / tw, rem = num_wtiles - qq * tw;
+    const int tw = (int)gridDim.x * WV, qq = num_wtiles / tw, rem = num_wtiles - qq * tw;
     agg_t0 = gwave * qq + (gwave < rem ? gwave : rem);
     agg_cnt = qq + (gwave < rem ? 1 : 0);
-    iters = qq + ((int)blockIdx.x * W16 < rem ? 1 : 0);
+    iters = qq + ((int)blockIdx.x * WV < rem ? 1 : 0);
   } else {
     iters = (num_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   }
   auto wtile_of = [&](int k) -> int {  // wave tile of iteration k (>= num_wtiles: past the end)
     if constexpr (AGG) return k < agg_cnt ? agg_t0 + k : num_wtiles;
-    return ((int)blockIdx.x + k * (int)gridDim.x) * W16 + wave;
+    return ((int)blockIdx.x + k * (int)gridDim.x) * WV + wave;
   };
   auto load_idx = [&](int wt_, int s) -> int {
     const int tc = wt_ < last_wt ? wt_ : last_wt;
@@ -417,28 +420,28 @@ __global__ __launch_bounds__(NT16) void mlp_stream16_kernel(const gnc_mlp_desc_t
   }
 }
 
-template <int NTH, int NTO, bool AGG = false, bool SAVE = false>
+template <int NTH, int NTO, bool AGG = false, bool SAVE = false, int WV = W16>
 int launch16(const gnc_mlp_desc_t& d, const Plan16& pl, hipStream_t stream) {
   constexpr int NTW = NTH > NTO ? NTH : NTO;
   constexpr bool DBUF = NTW <= 8;
   const size_t smem =
-      ((size_t)(DBUF ? 2 : 1) * NTW * 16 * LDSW + (size_t)(d.num_linear + 2) * NTW * 16 + (size_t)W16 * R16 * LDSW) * sizeof(float);
+      ((size_t)(DBUF ? 2 : 1) * NTW * 16 * LDSW + (size_t)(d.num_linear + 2) * NTW * 16 + (size_t)WV * R16 * LDSW) * sizeof(float);
   if (smem > 160 * 1024) {
     gnc::set_error("mlp_stream16: LDS budget exceeded (%zu bytes)", smem);
     return GNC_ERR_UNSUPPORTED;
   }
   static bool attr_set = false;
   if (!attr_set) {
-    int rc = gnc::check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_stream16_kernel<NTH, NTO, DBUF, AGG, SAVE>),
+    int rc = gnc::check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_stream16_kernel<NTH, NTO, DBUF, AGG, SAVE, WV>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
                             "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc) return rc;
     attr_set = true;
   }
-  const int64_t num_tiles = gnc::ceil_div(d.rows, (int64_t)W16 * R16);
+  const int64_t num_tiles = gnc::ceil_div(d.rows, (int64_t)WV * R16);
   int64_t grid = num_tiles < gnc::num_cu() ? num_tiles : gnc::num_cu();
   if constexpr (AGG) grid = gnc::num_cu();  // agg_fix has two entries for every wave of the full grid (8 waves per workgroup)
-  mlp_stream16_kernel<NTH, NTO, DBUF, AGG, SAVE><<<dim3((unsigned)grid), dim3(NT16), smem, stream>>>(d, pl, (int)num_tiles);
+  mlp_stream16_kernel<NTH, NTO, DBUF, AGG, SAVE, WV><<<dim3((unsigned)grid), dim3(WV * 64), smem, stream>>>(d, pl, (int)num_tiles);
   return gnc::check_launch("mlp_stream16_kernel");
 }
 
@@ -486,17 +489,31 @@ int gnc_mlp::launch_stream16(const gnc_mlp_desc_t& d, hipStream_t stream, bool* 
       if (pl.num_wchunks >= MAX_WCHUNKS16) return GNC_OK;
       pl.wc[pl.num_wchunks++] = {(short)l, (short)(c * KC), (short)d.in_dim[l], 0};
     }
-  const bool save = d.save_act[0] != nullptr;  // training forward: SAVE instances of the 256-wide kernel (template flag)
-  if (save && !(H > 128 && od > 16)) return GNC_OK;
-  if (d.agg_out) {  // aggregation epilogue: the 256-wide instance only (129..256 output features), rows < 2^31 / 16
-    if (!(od > 128 && L > 1) || !d.agg_index || !d.agg_fix || d.ld_agg < od) return GNC_OK;
+  const bool save = d.save_act[0] != nullptr;  // training forward: SAVE instances (template flag) of the 256-wide kernel and of the small-batch one
+  const bool small_rows = d.rows <= (int64_t)2 * R16 * gnc::num_cu();
+  if (save && !((H > 128 || (small_rows && H > 64)) && od > 16)) return GNC_OK;
+  // small batches at up to 128 features (the reference's one-graph-per-call regime): 2-wave workgroups of 16-row tiles
+  const bool small128 = H <= 128 && od <= 128 && (!save || od > 16) && d.rows <= (int64_t)2 * R16 * gnc::num_cu();
+  if (d.agg_out) {  // aggregation epilogue: the 256-wide instance (129..256 output features) and the small-batch 128-wide one
+    if (L <= 1 || !d.agg_index || !d.agg_fix || d.ld_agg < od) return GNC_OK;
+    if (small128 && od > 64) {
+      *launched = true;
+      if (probe_only) return GNC_OK;
+      return save ? launch16<8, 8, true, true, 2>(d, pl, stream) : launch16<8, 8, true, false, 2>(d, pl, stream);
+    }
+    if (!(od > 128)) return GNC_OK;
     *launched = true;
     if (probe_only) return GNC_OK;
     return save ? launch16<16, 16, true, true>(d, pl, stream) : launch16<16, 16, true>(d, pl, stream);
   }
   *launched = true;
   if (probe_only) return GNC_OK;
+  if (save && small128) return launch16<8, 8, false, true, 2>(d, pl, stream);
   if (save) return launch16<16, 16, false, true>(d, pl, stream);
+  if (small128) {
+    if (od <= 16 && L > 1) return launch16<8, 1, false, false, 2>(d, pl, stream);
+    return launch16<8, 8, false, false, 2>(d, pl, stream);
+  }
   if (H <= 128 && od <= 128) {
     if (od <= 16 && L > 1) return launch16<8, 1>(d, pl, stream);
     return launch16<8, 8>(d, pl, stream);
