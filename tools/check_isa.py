@@ -154,7 +154,12 @@ def main():
     ap.add_argument("--objects", default=os.path.join(ROOT, "build", "csrc", "*.o"))
     ap.add_argument("-v", "--verbose", action="store_true")
     a = ap.parse_args()
-    objs = sorted(o for o in glob.glob(a.objects) if not o.endswith("_probe.o"))  # developer probe builds are not shipped
+    objs = sorted(glob.glob(a.objects))
+    mk = os.path.join(ROOT, "graphnet_classifier_amd", "csrc", "Makefile")
+    m = re.search(r"^SRCS\s*=\s*(.+)$", open(mk).read(), re.M) if os.path.exists(mk) else None
+    if m:  # only the objects the shared library links: probe / variant builds left in build/csrc are not shipped
+        shipped = {s[:-4] + ".o" for s in m.group(1).split() if s.endswith(".hip")}
+        objs = [o for o in objs if os.path.basename(o) in shipped]
     if not objs:
         print("check_isa: no objects under build/csrc (run make first)")
         return 1
