@@ -775,6 +775,9 @@ int launch_stream(const gnc_mlp_desc_t& d, int T, bool narrow_out, hipStream_t s
                   bool probe_only = false);
 // widths 129..256 on v_mfma_f32_16x16x4_f32, 16 rows per wave (mlp_stream16.hip); same contract
 int launch_stream16(const gnc_mlp_desc_t& d, hipStream_t stream, bool* launched, bool probe_only = false);
+// small batches (rows <= col16_max_rows()) at up to 128 features: column-split workgroups, mlp_col16.hip
+int launch_col16(const gnc_mlp_desc_t& d, hipStream_t stream, bool* launched, bool probe_only = false);
+int64_t col16_max_rows();
 // K8 data kernel for widths 129..256 on 16-row tiles (mlp_backward16.hip): shape query / launch
 bool bwd_stream16_supported(const gnc_mlp_desc_t& d, bool want_dx);
 int bwd_stream16_ln_partial_rows(int64_t rows);

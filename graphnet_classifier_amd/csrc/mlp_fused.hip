@@ -271,7 +271,9 @@ extern "C" int gnc_mlp_agg_supported(const gnc_mlp_desc_t* desc) {
   if (!probe.agg_fix) probe.agg_fix = &dummy_i;
   if (probe.ld_agg < od) probe.ld_agg = od;
   bool ok = false;
-  rc = launch_resident(probe, T, narrow_out, nullptr, &ok, true);
+  rc = launch_col16(probe, nullptr, &ok, true);
+  if (rc) return rc;
+  if (!ok) rc = launch_resident(probe, T, narrow_out, nullptr, &ok, true);
   if (rc) return rc;
   if (!ok && T == 4) {  // 65..128 features: the streaming kernel carries the epilogue too
     rc = launch_stream(probe, T, narrow_out, nullptr, &ok, true);
@@ -313,8 +315,10 @@ extern "C" int gnc_mlp_save_act_supported(const gnc_mlp_desc_t* desc) {
   for (int l = 0; l < L - 1; ++l)
     if (!probe.save_act[l]) probe.save_act[l] = dummy_f;
   bool ok = false;
-  if (L >= 2) {  // the dispatch chain of gnc_mlp_forward_f32: resident, 16-row streaming (129..256), 32-row streaming
-    rc = launch_resident(probe, T, narrow_out, nullptr, &ok, true);
+  if (L >= 2) {  // the dispatch chain of gnc_mlp_forward_f32: column split, resident, 16-row streaming (129..256), 32-row streaming
+    rc = launch_col16(probe, nullptr, &ok, true);
+    if (rc) return rc;
+    if (!ok) rc = launch_resident(probe, T, narrow_out, nullptr, &ok, true);
     if (rc) return rc;
     static const bool s16_128 = getenv("GNC_STREAM16_D128") != nullptr;
     if (!ok && (T == 8 || (T == 4 && s16_128 && !probe.agg_out) || small16(probe, T))) {
@@ -345,8 +349,10 @@ extern "C" int gnc_mlp_forward_f32(const gnc_mlp_desc_t* desc, void* stream_) {
   const bool narrow_out = od <= 32;
   if (!narrow_out && tiles_for(od) > T) T = tiles_for(od);
 
-  bool launched = false;  // weights-resident variant first (decides by LDS fit)
-  rc = launch_resident(*desc, T, narrow_out, stream, &launched);
+  bool launched = false;
+  rc = launch_col16(*desc, stream, &launched);  // small batches at 65..128 features: column-split workgroups
+  if (rc || launched) return rc;
+  rc = launch_resident(*desc, T, narrow_out, stream, &launched);  // weights-resident variant (decides by LDS fit)
   if (rc || launched) return rc;
   if (desc->agg_out && T != 4 && T != 8) {
     gnc::set_error("gnc_mlp_forward_f32: the fused aggregation epilogue is not available for this description "
