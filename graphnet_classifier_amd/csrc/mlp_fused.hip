@@ -338,6 +338,23 @@ extern "C" int gnc_mlp_save_act_supported(const gnc_mlp_desc_t* desc) {
   return GNC_OK;
 }
 
+// shape + alignment answer: 0 when the small-batch (column-split) kernel serves this description exactly as given - it is
+// the only kernel that reads tables and weights whose rows are not 16-B pieces (3-column inputs, [H, 3] weights) in place
+extern "C" int gnc_mlp_small_batch_supported(const gnc_mlp_desc_t* desc) {
+  int rc = validate_desc(desc, false);
+  if (rc) return rc;
+  bool ok = false;
+  if (desc->rows > 0) {
+    rc = launch_col16(*desc, nullptr, &ok, true);
+    if (rc) return rc;
+  }
+  if (!ok) {
+    gnc::set_error("gnc_mlp_small_batch_supported: not a small-batch description (rows, widths <= 128, ReLU)");
+    return GNC_ERR_UNSUPPORTED;
+  }
+  return GNC_OK;
+}
+
 extern "C" int gnc_mlp_forward_f32(const gnc_mlp_desc_t* desc, void* stream_) {
   int rc = validate_desc(desc, true);
   if (rc) return rc;

@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 GNC_MAX_SEGMENTS = 4
 GNC_MAX_LINEAR = 8
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 ACTIVATIONS = {  # nn.<Name> accepted by the reference's MLP(activation=...) (models/MLP.py:21)
     "ReLU": 0, "Identity": 1, "Tanh": 2, "Sigmoid": 3, "SiLU": 4, "GELU": 5, "LeakyReLU": 6, "ELU": 7,
@@ -32,6 +32,7 @@ _SIGNATURES = {
     "gnc_mlp_agg_supported": (c_int32, [c_void_p]),
     "gnc_mlp_save_act_supported": (c_int32, [c_void_p]),
     "gnc_mlp_agg_fix_len": (c_int32, []),
+    "gnc_mlp_small_batch_supported": (c_int32, [c_void_p]),
     "gnc_agg_fixup_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p, c_int64,
                                     c_void_p]),
     "gnc_csr_workspace_bytes": (c_size_t, [c_int64, c_int64]),
@@ -434,13 +435,15 @@ def _vector_rows(t: torch.Tensor) -> torch.Tensor:
     return torch.nn.functional.pad(t, (0, cols - t.size(1)))[:, :t.size(1)]
 
 
-def _prepare_mlp(segments, weights, biases, residual, rows, modes):
-    """Shared argument preparation of the forward and backward launches (see mlp_forward)."""
+def _prepare_mlp(segments, weights, biases, residual, rows, modes, vector_rows: bool = True):
+    """Shared argument preparation of the forward and backward launches (see mlp_forward).  ``vector_rows=False`` hands
+    tables and weights over as they are (row-major, any alignment): only for a launch the small-batch kernel takes."""
+    _vr = _vector_rows if vector_rows else (lambda t: t)
     modes = list(modes) if modes is not None else [SEG_MATMUL] * len(segments)
     segs, wcol = [], 0
     for (table, index), mode in zip(segments, modes):
         _require_cuda(table, index)
-        table = _vector_rows(_rowmajor(table))
+        table = _vr(_rowmajor(table))
         if index is not None and index.dtype != torch.int32:
             raise TypeError("segment index must be int32")
         segs.append((table, index, table.size(1), mode, wcol if mode == SEG_MATMUL else 0))
@@ -456,7 +459,7 @@ def _prepare_mlp(segments, weights, biases, residual, rows, modes):
     if rows is None:
         t0, i0 = segments[0]
         rows = i0.numel() if i0 is not None else t0.size(0)
-    weights = [_vector_rows(_rowmajor(w.detach())) for w in weights]
+    weights = [_vr(_rowmajor(w.detach())) for w in weights]
     biases = [b.contiguous() if b is not None else None for b in biases]
     if residual is not None:
         residual = _rowmajor(residual)
@@ -500,10 +503,16 @@ def mlp_forward(segments, weights, biases, ln=None, activation: str = "ReLU", ac
     ``mlp_backward(saved_act=...)``, which then reads them instead of recomputing the forward of every tile;
     ``save_need_dx`` says whether that backward will want the input gradient (``need_dx``)."""
     lib = load_library()
-    segs, weights, biases, residual, rows, modes = _prepare_mlp(segments, weights, biases, residual, rows, modes)
+    given = (segments, weights, biases, residual, rows, modes)
+    segs, weights, biases, residual, rows, modes = _prepare_mlp(*given, vector_rows=False)
     dev = segs[0][0].device
     out = torch.empty(rows, weights[-1].size(0), dtype=torch.float32, device=dev)
     desc = make_mlp_desc(segs, weights, biases, ln, activation, act_param, residual, out, rows)
+    if lib.gnc_mlp_small_batch_supported(ctypes.byref(desc)) != 0:
+        # every other kernel reads rows as 16-B pieces: 3-column inputs / [H, 3] weights go through a zero-padded copy
+        # (one pad launch each); the small-batch kernel reads them where they lie
+        segs, weights, biases, residual, rows, modes = _prepare_mlp(*given)
+        desc = make_mlp_desc(segs, weights, biases, ln, activation, act_param, residual, out, rows)
     if (save_act is not None and SAVE_ACT and rows > 0 and len(weights) >= 2
             and lib.gnc_mlp_save_act_supported(ctypes.byref(desc)) == 0 and _backward_reads_saved_act(lib, desc, out, save_need_dx)):
         for l in range(len(weights) - 1):

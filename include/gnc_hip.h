@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GNC_ABI_VERSION 17
+#define GNC_ABI_VERSION 18
 
 enum {
   GNC_OK = 0,
@@ -229,6 +229,12 @@ int gnc_mlp_forward_f32(const gnc_mlp_desc_t* desc /* host */, void* stream);
 /* fused aggregation epilogue: 0 if this description can run with agg_out set (shape fields only) */
 int gnc_mlp_agg_supported(const gnc_mlp_desc_t* desc /* host */);
 int gnc_mlp_agg_fix_len(void); /* entries of agg_fix (2 per wave of the persistent grid) */
+/* ABI 18.  0 if the small-batch kernel (one 16-row tile per workgroup, the waves split the output features; rows up to
+ * 32 x the number of CUs, widths 65..128, ReLU) serves this description EXACTLY AS GIVEN: it is the only kernel that reads
+ * tables and weights whose rows are not 16-B pieces (the reference's [N, 3] inputs and nn.Linear(3, H) weights,
+ * models/GNN.py:251-253) in place; for every other launch the caller hands over zero-padded copies.  The reference's own
+ * regime (one graph per call: main.py:60, utils/train_model.py:35-45, utils/inference.py:59) runs on it. */
+int gnc_mlp_small_batch_supported(const gnc_mlp_desc_t* desc /* host */);
 /* 0 if gnc_mlp_forward_f32 can run this description with save_act set (every kernel but the generic fallback: ReLU, hidden
  * widths that are multiples of 4 and at most 256, aligned tables), GNC_ERR_UNSUPPORTED otherwise (shape fields only) */
 int gnc_mlp_save_act_supported(const gnc_mlp_desc_t* desc /* host */);
