@@ -600,6 +600,12 @@ def mlp_backward(segments, weights, biases, ln, grad_out: torch.Tensor | None, r
                 bd.act[l] = None
             bd.act_given = 0
         bd.dx = None
+        if bd.act_given:  # the shape queries that only see the forward description learn about the saved rows this way
+            for l, a in enumerate(saved_act):
+                bd.fwd.save_act[l] = a.data_ptr()
+            fold = (residual is not None and need_dx and mm[-1][1] is None and mm[-1][0].data_ptr() == residual.data_ptr()
+                    and mm[-1][2] == w[-1].size(0) and lib.gnc_mlp_backward_dx_add_honoured(ctypes.byref(bd.fwd)) == 1)
+            bd.dx_add_grad_out = 1 if fold else 0
     gt = gi = None
     if grad_gather is not None:
         gt, gi = _vector_rows(_rowmajor(grad_gather[0])), grad_gather[1]
@@ -676,14 +682,14 @@ def mlp_backward(segments, weights, biases, ln, grad_out: torch.Tensor | None, r
             bd.yhat = yhat.data_ptr()
     flops = 2.0 * rows * (2 * sum(x.size(0) * x.size(1) for x in w))
     with torch.cuda.device(dev):
-        _check(_launch(f"mlp_backward_in{w[0].size(1)}_h{w[0].size(0)}_out{w[-1].size(0)}_L{n_lin}", g,
-                       lambda: lib.gnc_mlp_backward_f32(ctypes.byref(bd), _stream(g)), flops), "gnc_mlp_backward_f32")
+        _check(_launch(f"mlp_backward_in{w[0].size(1)}_h{w[0].size(0)}_out{w[-1].size(0)}_L{n_lin}", launch_ref,
+                       lambda: lib.gnc_mlp_backward_f32(ctypes.byref(bd), _stream(launch_ref)), flops), "gnc_mlp_backward_f32")
     ln_sums = None
     if ln_part is not None:
         tot = ln_part.sum(dim=0)  # fixed order: reproducible
         ln_sums = (tot[:w[-1].size(0)], tot[w[-1].size(0):])  # (d beta, d gamma)
     return {"act": act, "dz": dz, "dx": dx, "yhat": yhat, "ln_sums": ln_sums, "residual_folded": bool(fold), "grad_out": g_eff,
-            "saved_act_used": bool(bd.act_given), "_keep": (segs, w, b, g)}
+            "saved_act_used": bool(bd.act_given), "_keep": (segs, w, b, g, gt, gi, saved_act)}
 
 
 def _xty_spans(n: int, step: int):

@@ -314,6 +314,10 @@ typedef struct gnc_mlp_bwd_desc {
    * contiguous [rows, out_dim[l]]); the kernel reads them instead of recomputing the forward of every tile.  Only where
    * gnc_mlp_backward_saved_act_honoured() returns 1 (the fused data + weight-gradient kernel: dw_partial given). */
   int32_t act_given;
+  /* ABI 18: with act_given, fwd.save_act[l] carries the same pointers as act[l]: the shape queries that only take the forward
+   * description (gnc_mlp_backward_ln_partial_rows, gnc_mlp_backward_dx_add_honoured, gnc_mlp_backward_supported) then answer
+   * for the kernel that will run - small batches (rows <= 32 x CUs, widths 65..128) with saved activations run the column-split
+   * data kernel (mlp_bwd_col16.hip): one ln_partial row per 16-row tile, grad_gather and dx_add_grad_out folded in. */
 } gnc_mlp_bwd_desc_t;
 
 size_t gnc_sizeof_mlp_bwd_desc(void);
