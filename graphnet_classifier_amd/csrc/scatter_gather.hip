@@ -9,6 +9,8 @@
 // coalesced load and hand them to the lane groups by cross-lane reads, then each group walks
 // its segment in ascending sorted position k (= original edge order, the sort is stable) and
 // keeps the running sum in registers.  Every destination row is written exactly once.
+#include <stdlib.h>
+
 #include "gnc_common.h"
 
 namespace {
@@ -86,6 +88,38 @@ __global__ __launch_bounds__(gnc::kBlock) void scatter_sum_csr_vec4(
       }
     }
   }
+}
+
+// K1 for a small graph (the reference's one-graph-per-call regime): the kernel above gives a wave 64 destinations and, at
+// 128 features, walks them two at a time - 32 dependent rounds of (ids, rows) per wave while most of the chip is idle
+// (1024 nodes: 16 busy waves, 25..37 us).  Here every lane group takes ONE destination, so the launch is one chain of
+// row pointers -> ids -> rows per group.  Same sums in the same order (bit-identical).
+template <int LPR, bool HAS_PERM>
+__global__ __launch_bounds__(gnc::kBlock) void scatter_sum_csr_small(
+    const float* __restrict__ src, int64_t ld_src, const int32_t* __restrict__ rowptr,
+    const int32_t* __restrict__ perm, int32_t num_nodes, int32_t feat_dim, float* __restrict__ out,
+    int64_t ld_out) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t v = tid / LPR;
+  const int col = (int)(tid % LPR) * 4;
+  if (v >= num_nodes || col >= feat_dim) return;
+  const int32_t start = rowptr[v], end = rowptr[v + 1];
+  f4 a = {0.f, 0.f, 0.f, 0.f};
+  int32_t k = start;
+  for (; k + 4 <= end; k += 4) {
+    int32_t i0 = k, i1 = k + 1, i2 = k + 2, i3 = k + 3;
+    if (HAS_PERM) { i0 = perm[k]; i1 = perm[k + 1]; i2 = perm[k + 2]; i3 = perm[k + 3]; }
+    const f4 r0 = ld4(src + (int64_t)i0 * ld_src + col);
+    const f4 r1 = ld4(src + (int64_t)i1 * ld_src + col);
+    const f4 r2 = ld4(src + (int64_t)i2 * ld_src + col);
+    const f4 r3 = ld4(src + (int64_t)i3 * ld_src + col);
+    acc4(a, r0); acc4(a, r1); acc4(a, r2); acc4(a, r3);  // ascending k: reference edge order
+  }
+  for (; k < end; ++k) {
+    const int32_t i0 = HAS_PERM ? perm[k] : k;
+    acc4(a, ld4(src + (int64_t)i0 * ld_src + col));
+  }
+  st4(out + v * ld_out + col, a);
 }
 
 // Fix-up of the fused aggregation epilogue (mlp_resident.hip): the few destinations cut by a wave's row-range
@@ -235,6 +269,24 @@ int launch_scatter(const float* src, int64_t ld_src, const int32_t* rowptr, cons
   const int64_t chunks = gnc::ceil_div(n, kChunk);
   const int waves_per_block = gnc::kBlock / kWave;
   if (vec4_ok(src, ld_src, d) && vec4_ok(out, ld_out, d)) {
+    static const bool no_small = getenv("GNC_NO_SMALL_K1") != nullptr;  // A/B switch
+    if (!no_small && n <= 64 * gnc::num_cu()) {  // a small graph: one lane group per destination
+      const int lpr = pow2_lanes_for(d);
+      const int64_t threads = (int64_t)n * lpr;
+      dim3 grid((unsigned)gnc::ceil_div(threads, (int64_t)gnc::kBlock)), block(gnc::kBlock);
+      switch (lpr) {
+#define GNC_CASE(L)                                                                                                \
+  case L:                                                                                                          \
+    scatter_sum_csr_small<L, HAS_PERM><<<grid, block, 0, stream>>>(src, ld_src, rowptr, perm, n, d, out, ld_out); \
+    break;
+        GNC_CASE(1) GNC_CASE(2) GNC_CASE(4) GNC_CASE(8) GNC_CASE(16) GNC_CASE(32) GNC_CASE(64)
+#undef GNC_CASE
+        default:
+          gnc::set_error("scatter_sum: internal lane mapping error for D=%d", d);
+          return GNC_ERR_UNSUPPORTED;
+      }
+      return gnc::check_launch("scatter_sum_csr_small");
+    }
     int64_t blocks = gnc::ceil_div(chunks, waves_per_block);
     const int64_t cap = gnc::num_cu() * 16;
     if (blocks > cap) blocks = cap;

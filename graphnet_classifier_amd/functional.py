@@ -157,7 +157,8 @@ def _fused_mlp_backward_hip(meta: _MlpMeta, args, need, grad_out, saved_act=None
         return None
     grad_out = grad_out.contiguous()
     need_tables = any(need[:s])
-    r = native.mlp_backward(segments, weights, biases, ln, grad_out, rows=meta.rows, need_dx=need_tables, saved_act=saved_act)
+    r = native.mlp_backward(segments, weights, biases, ln, grad_out, rows=meta.rows, need_dx=need_tables, saved_act=saved_act,
+                            defer_ln_sums=True)
     grads = [None] * len(args)
     # inputs: dx is in concat (= weight column) order
     off = 0
@@ -176,7 +177,9 @@ def _fused_mlp_backward_hip(meta: _MlpMeta, args, need, grad_out, saved_act=None
                 csr = get_destination_csr(idx, t.size(0), t.device)
                 grads[k] = native.scatter_sum_csr(gk, csr.rowptr, csr.perm, t.size(0))
         off += w
-    # weights and biases: dW_l = dz_l^T (input of Linear l), db_l = column sums of dz_l
+    # weights and biases: dW_l = dz_l^T (input of Linear l), db_l = column sums of dz_l - every product of this MLP (and
+    # the row sums of its LayerNorm partials) in one xty_multi call: one launch for a small batch
+    products, slots = [], []
     for k in range(l):
         if not (need[s + k] or need[s + l + k]):
             continue
@@ -186,19 +189,30 @@ def _fused_mlp_backward_hip(meta: _MlpMeta, args, need, grad_out, saved_act=None
             continue
         dz = r["dz"][k]
         if k == 0:
-            parts, db = [], None
-            for rows_k in layer0_inputs:
-                c, cs = native.xty(dz, rows_k)
-                parts.append(c)
-                db = cs if db is None else db
-            dw = torch.cat(parts, dim=1) if len(parts) > 1 else parts[0]
+            dw = torch.empty(weights[0].size(0), sum(t.size(1) for t in layer0_inputs), dtype=torch.float32, device=dz.device)
+            off = 0
+            for rows_k in layer0_inputs:  # column blocks of dW_0, in concat order
+                products.append((dz, rows_k, dw[:, off:off + rows_k.size(1)]))
+                slots.append((k, off == 0))
+                off += rows_k.size(1)
+            grads[s + k] = dw if need[s + k] else None
         else:
-            dw, db = native.xty(dz, r["act"][k - 1])
-        grads[s + k] = dw if need[s + k] else None
-        grads[s + l + k] = db if need[s + l + k] else None
+            products.append((dz, r["act"][k - 1], None))
+            slots.append((k, True))
+    ln_part = r.get("ln_part")
+    res, sums = native.xty_multi(products, [ln_part] if ln_part is not None else []) if (products or ln_part is not None) else ([], [])
+    for (k, first), (c, cs) in zip(slots, res):
+        if k > 0:
+            grads[s + k] = c if need[s + k] else None
+        if first:
+            grads[s + l + k] = cs if need[s + l + k] else None
     pos = s + 2 * l
     if meta.has_ln:
-        dbeta, dgamma = r["ln_sums"] if r["ln_sums"] is not None else native.colsum_pair(grad_out, r["yhat"])
+        if ln_part is not None:
+            od = ln_part.size(1) // 2
+            dbeta, dgamma = sums[0][:od], sums[0][od:]
+        else:
+            dbeta, dgamma = r["ln_sums"] if r["ln_sums"] is not None else native.colsum_pair(grad_out, r["yhat"])
         grads[pos] = dgamma if need[pos] else None
         grads[pos + 1] = dbeta if need[pos + 1] else None
         pos += 2
@@ -407,7 +421,7 @@ def _edge_wsplit_backward_hip(ctx, grad_out, grad_agg=None):
     r = native.mlp_backward(segments, wl, biases, ln, grad_out.contiguous() if grad_out is not None else None, rows=e.size(0),
                             modes=modes, need_dx=bool(need[1]), residual=e,
                             grad_gather=(grad_agg.contiguous(), dst) if grad_agg is not None else None,
-                            saved_act=extra[2:] or None)
+                            saved_act=extra[2:] or None, defer_ln_sums=True)
     grad_out = r["grad_out"]  # effective row-ordered gradient (None when the launch gathered part of it itself)
     dz0 = r["dz"][0]
     grads = [None] * (2 + len(params))
@@ -420,18 +434,41 @@ def _edge_wsplit_backward_hip(ctx, grad_out, grad_agg=None):
     if need[0]:  # dx = dps Ws + dpd Wd: one projection launch over [dps | dpd] with the weight [Ws ; Wd]^T
         wt = torch.cat([ws_, wd_], dim=0).t().contiguous()  # [dn, 2h]
         grads[0] = native.mlp_forward([(dps, None), (dpd, None)], [wt], [None])
+    # every weight-gradient product of this processor (and the row sums of its LayerNorm partials) in one xty_multi call:
+    # one launch for a small batch; dW_0 = [dps^T x | dpd^T x | dz0^T e] is written block by block in place
+    products, slots = [], []
     if need[2] or need[2 + num_linear]:
-        dws, _ = native.xty(dps, x)
-        dwd, _ = native.xty(dpd, x)
-        dwe, db0 = (r["dw"][0], r["db"][0]) if "dw" in r else native.xty(dz0, e)
-        grads[2] = torch.cat([dws, dwd, dwe], dim=1)
-        grads[2 + num_linear] = db0
+        dw0 = torch.empty(h, 2 * dn + e.size(1), dtype=torch.float32, device=e.device)
+        products += [(dps, x, dw0[:, :dn]), (dpd, x, dw0[:, dn:2 * dn])]
+        slots += [None, None]
+        if "dw" in r:
+            dw0[:, 2 * dn:] = r["dw"][0]
+            grads[2 + num_linear] = r["db"][0]
+        else:
+            products.append((dz0, e, dw0[:, 2 * dn:]))
+            slots.append(("b", 0))
+        grads[2] = dw0
     for k in range(1, num_linear):
-        dw, db = (r["dw"][k], r["db"][k]) if "dw" in r else native.xty(r["dz"][k], r["act"][k - 1])
-        grads[2 + k] = dw
-        grads[2 + num_linear + k] = db
+        if "dw" in r:
+            grads[2 + k], grads[2 + num_linear + k] = r["dw"][k], r["db"][k]
+        else:
+            products.append((r["dz"][k], r["act"][k - 1], None))
+            slots.append(("wb", k))
+    ln_part = r.get("ln_part")
+    res, sums = native.xty_multi(products, [ln_part] if ln_part is not None else [])
+    for slot, (c, cs) in zip(slots, res):
+        if slot is None:
+            continue
+        kind, k = slot
+        if kind == "wb":
+            grads[2 + k] = c
+        grads[2 + num_linear + k] = cs
     if has_ln:
-        dbeta, dgamma = r["ln_sums"] if r["ln_sums"] is not None else native.colsum_pair(grad_out, r["yhat"])
+        if ln_part is not None:
+            od = ln_part.size(1) // 2
+            dbeta, dgamma = sums[0][:od], sums[0][od:]
+        else:
+            dbeta, dgamma = r["ln_sums"] if r["ln_sums"] is not None else native.colsum_pair(grad_out, r["yhat"])
         grads[2 + 2 * num_linear] = dgamma
         grads[2 + 2 * num_linear + 1] = dbeta
     return tuple(g if n else None for g, n in zip(grads, need))

@@ -33,6 +33,8 @@ _SIGNATURES = {
     "gnc_mlp_save_act_supported": (c_int32, [c_void_p]),
     "gnc_mlp_agg_fix_len": (c_int32, []),
     "gnc_mlp_small_batch_supported": (c_int32, [c_void_p]),
+    "gnc_xty_small_max_rows": (c_int32, []),
+    "gnc_xty_small_f32": (c_int32, [c_void_p, c_int32, c_void_p]),
     "gnc_agg_fixup_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p, c_int64,
                                     c_void_p]),
     "gnc_csr_workspace_bytes": (c_size_t, [c_int64, c_int64]),
@@ -113,6 +115,13 @@ class MlpBwdDesc(Structure):
         ("grad_sum", c_void_p), ("ld_grad_sum", c_int32), ("act_given", c_int32),
     ]
 
+
+class XtyJob(Structure):
+    _fields_ = [("a", c_void_p), ("lda", c_int64), ("b", c_void_p), ("ldb", c_int64), ("rows", c_int64), ("m", c_int32),
+                ("k", c_int32), ("dw", c_void_p), ("ld_dw", c_int64), ("db", c_void_p), ("kind", c_int32)]
+
+
+GNC_XTY_MAX_JOBS = 8
 
 _lib = None
 
@@ -556,7 +565,7 @@ def mlp_backward_supported(segments, weights, biases, ln, activation, residual, 
 
 def mlp_backward(segments, weights, biases, ln, grad_out: torch.Tensor | None, rows: int | None = None, modes=None,
                  need_dx: bool = True, residual: torch.Tensor | None = None, fused: bool = True, grad_gather=None,
-                 saved_act=None):
+                 saved_act=None, defer_ln_sums: bool = False):
     """Data path of the MLP backward (see include/gnc_hip.h, K8).  Returns a dict with
     ``act`` (inputs of Linear 1..L-1), ``dz`` (grads of every pre-activation, dz[-1] = pre-LayerNorm),
     ``dx`` ([rows, in_dim0] in weight-column order, or None) and ``yhat`` (or None).  Shapes of the fused kernel
@@ -568,6 +577,9 @@ def mlp_backward(segments, weights, biases, ln, grad_out: torch.Tensor | None, r
     output rows (models/GNN.py:99).  Kernels that honour it (gnc_mlp_backward_grad_gather_honoured) gather inside the
     launch; otherwise the rows are gathered here first (K2).  ``r["grad_out"]`` is the effective row-ordered gradient when
     it had to be materialised, else None.
+
+    ``defer_ln_sums``: leave the per-worker LayerNorm partial sums unsummed in ``r["ln_part"]`` ([P, 2 * out_dim]: d beta |
+    d gamma) for the caller to fold into its ``xty_multi`` launch (split path only).
 
     ``saved_act``: the list ``mlp_forward(save_act=...)`` filled for the same call; kernels that honour it
     (gnc_mlp_backward_saved_act_honoured) read the post-activations instead of recomputing them."""
@@ -685,10 +697,11 @@ def mlp_backward(segments, weights, biases, ln, grad_out: torch.Tensor | None, r
         _check(_launch(f"mlp_backward_in{w[0].size(1)}_h{w[0].size(0)}_out{w[-1].size(0)}_L{n_lin}", launch_ref,
                        lambda: lib.gnc_mlp_backward_f32(ctypes.byref(bd), _stream(launch_ref)), flops), "gnc_mlp_backward_f32")
     ln_sums = None
-    if ln_part is not None:
+    if ln_part is not None and not defer_ln_sums:
         tot = ln_part.sum(dim=0)  # fixed order: reproducible
         ln_sums = (tot[:w[-1].size(0)], tot[w[-1].size(0):])  # (d beta, d gamma)
-    return {"act": act, "dz": dz, "dx": dx, "yhat": yhat, "ln_sums": ln_sums, "residual_folded": bool(fold), "grad_out": g_eff,
+    return {"act": act, "dz": dz, "dx": dx, "yhat": yhat, "ln_sums": ln_sums, "ln_part": ln_part if defer_ln_sums else None,
+            "residual_folded": bool(bd.dx_add_grad_out), "grad_out": g_eff,
             "saved_act_used": bool(bd.act_given), "_keep": (segs, w, b, g, gt, gi, saved_act)}
 
 
@@ -728,6 +741,62 @@ def xty(a: torch.Tensor, b: torch.Tensor):
                                                colsum[m0:m0 + mm].data_ptr() if k0 == 0 else None, _stream(av)),
                    "gnc_reduce_partials_f32")
     return c, colsum
+
+
+def xty_multi(products, row_sums=()):
+    """Several weight-gradient products at once.  ``products``: list of ``(a [rows, M], b [rows, K], out)`` with ``out`` an
+    [M, K] view to write into (any row stride: a column block of a wider gradient) or None for a fresh tensor; returns the
+    list of ``(a^T b, column sums of a)``.  ``row_sums``: list of [P, W] tensors (per-tile partial sums); their row sums
+    [W] are returned as a second list.  Small batches (every operand within gnc_xty_small_max_rows rows: the reference's
+    one-graph-per-step regime) run as ONE launch per 8 jobs (gnc_xty_small_f32); anything else goes product by product
+    through ``xty``."""
+    lib = load_library()
+    products = [(_rowmajor(a), _rowmajor(b), out) for a, b, out in products]
+    row_sums = [_rowmajor(p) for p in row_sums]
+    lim = lib.gnc_xty_small_max_rows()
+    small = (all(a.size(0) <= lim and a.size(0) >= 1 and a.size(1) <= 4096 and b.size(1) <= 4096 for a, b, _ in products)
+             and all(1 <= p.size(0) <= lim for p in row_sums) and (products or row_sums))
+    if not small:
+        res = []
+        for a, b, out in products:
+            c, cs = xty(a, b)
+            if out is not None:
+                out.copy_(c)
+                c = out
+            res.append((c, cs))
+        return res, [p.sum(dim=0) for p in row_sums]
+    dev = (products[0][0] if products else row_sums[0]).device
+    _require_cuda(*[t for a, b, _ in products for t in (a, b)], *row_sums)
+    jobs, res, sums = [], [], []
+    for a, b, out in products:
+        m, k = a.size(1), b.size(1)
+        if a.size(0) != b.size(0):
+            raise ValueError("xty_multi: operands of one product must have the same number of rows")
+        if out is None:
+            out = torch.empty(m, k, dtype=torch.float32, device=dev)
+        elif out.shape != (m, k) or out.stride(1) != 1 or out.dtype != torch.float32:
+            raise ValueError("xty_multi: out must be a float32 [M, K] view with unit column stride")
+        cs = torch.empty(m, dtype=torch.float32, device=dev)
+        j = XtyJob()
+        j.a, j.lda, j.b, j.ldb, j.rows, j.m, j.k = a.data_ptr(), _ld(a), b.data_ptr(), _ld(b), a.size(0), m, k
+        j.dw, j.ld_dw, j.db, j.kind = out.data_ptr(), out.stride(0), cs.data_ptr(), 0
+        jobs.append(j)
+        res.append((out, cs))
+    for p in row_sums:
+        o = torch.empty(p.size(1), dtype=torch.float32, device=dev)
+        j = XtyJob()
+        j.a, j.lda, j.rows, j.m, j.dw, j.kind = p.data_ptr(), _ld(p), p.size(0), p.size(1), o.data_ptr(), 1
+        jobs.append(j)
+        sums.append(o)
+    with torch.cuda.device(dev):
+        for q in range(0, len(jobs), GNC_XTY_MAX_JOBS):
+            chunk = jobs[q:q + GNC_XTY_MAX_JOBS]
+            arr = (XtyJob * len(chunk))(*chunk)
+            flops = sum(2.0 * j.rows * j.m * j.k for j in chunk if j.kind == 0)
+            _check(_launch("xty_small", res[0][0] if res else sums[0],
+                           lambda: lib.gnc_xty_small_f32(ctypes.byref(arr), len(chunk), torch.cuda.current_stream(dev).cuda_stream),
+                           flops), "gnc_xty_small_f32")
+    return res, sums
 
 
 def colsum_pair(g: torch.Tensor, y: torch.Tensor):

@@ -347,6 +347,29 @@ int gnc_colsum_pair_f32(const float* G, int64_t ldg, const float* Y, int64_t ldy
 int gnc_reduce_partials_f32(const float* partial, int32_t num_partials, int32_t stride, int32_t M, int32_t K,
                             float* dW, int64_t ld_dw, float* db, void* stream);
 
+/* ---- weight gradients of a small batch (ABI 18) ------------------------------------------------------------
+ * The reference trains on one graph per step (utils/train_model.py:35-45): ~2000 rows per product.  gnc_xty_small_f32
+ * forms SEVERAL products in ONE launch, without partial buffers or a reduction launch:
+ *   kind 0:  dw[m, k] = sum over r of a[r, m] * b[r, k]   (dw [m, ld_dw]; any row stride, so a block of a wider matrix)
+ *            db[m]    = sum over r of a[r, m]             (db may be NULL)
+ *   kind 1:  dw[c]    = sum over r of a[r, c], c < m      (rows of per-tile partial sums -> one row; b, k, db unused)
+ * Sums run in a fixed order (bitwise reproducible).  rows <= gnc_xty_small_max_rows() for every job. */
+#define GNC_XTY_MAX_JOBS 8
+typedef struct gnc_xty_job {
+  const float* a;
+  int64_t lda;
+  const float* b;
+  int64_t ldb;
+  int64_t rows;
+  int32_t m, k;
+  float* dw;
+  int64_t ld_dw;
+  float* db;
+  int32_t kind;
+} gnc_xty_job_t;
+int gnc_xty_small_max_rows(void);
+int gnc_xty_small_f32(const gnc_xty_job_t* jobs /* host */, int32_t num_jobs, void* stream);
+
 /* ---- backward of an MLP with an activation other than ReLU (ABI 17) ---------------------------------------
  * models/MLP.py:21 accepts any nn.<Name>; the reference's entry points only use ReLU, which the fused K8 kernels
  * above serve.  For the other activations of GNC_ACT_* the backward runs LAYER BY LAYER on this library: the
