@@ -551,6 +551,17 @@ def mlp_forward(segments, weights, biases, ln=None, activation: str = "ReLU", ac
     return (out, agg) if aggregate is not None else out
 
 
+def small_batch_kernel_serves(segments, weights, biases, ln=None, activation: str = "ReLU", residual=None, rows=None,
+                              modes=None) -> bool:
+    """Would the small-batch (column-split) kernel run this ``mlp_forward`` call as its operands lie
+    (gnc_mlp_small_batch_supported)?  The reference's one-graph-per-call regime is served by it."""
+    lib = load_library()
+    segs, w, b, res, rows, _ = _prepare_mlp(segments, weights, biases, residual, rows, modes, vector_rows=False)
+    dummy = torch.empty(max(rows, 1), w[-1].size(0), device=segs[0][0].device)
+    desc = make_mlp_desc(segs, w, b, ln, activation, 0.0, res, dummy, rows)
+    return lib.gnc_mlp_small_batch_supported(ctypes.byref(desc)) == 0
+
+
 # --------------------------------------------------------------------------- K8 backward
 def mlp_backward_supported(segments, weights, biases, ln, activation, residual, rows, modes=None) -> bool:
     """Shape query of the HIP backward kernel (ReLU, widths <= 64, 2..7 Linear layers ...)."""
