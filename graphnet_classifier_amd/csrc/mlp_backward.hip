@@ -1223,7 +1223,7 @@ extern "C" int gnc_mlp_backward_dx_add_honoured(const gnc_mlp_desc_t* fwd) {
   BwdPlan pl;
   static const bool off = getenv("GNC_NO_STREAM_DX_FOLD") != nullptr;  // A/B switch: the streaming kernels leave the add to the caller
   if (!fwd || validate_desc(fwd, false) != GNC_OK) return 0;
-  if (fwd->save_act[0] && fwd->num_linear >= 2 && bwd_col16_supported(*fwd)) return 1;
+  if (fwd->save_act[0] && fwd->num_linear >= 2 && (bwd_col16_supported(*fwd) || bwd_col16_persist_supported(*fwd))) return 1;
   if (bwd_shape(*fwd, &nmm, &nadd, &T)) return 1;
   return (!off && (bwd_stream_plan(*fwd, true, &pl, &T) || use_stream16(*fwd, true))) ? 1 : 0;
 }
@@ -1280,6 +1280,7 @@ extern "C" int gnc_mlp_backward_f32(const gnc_mlp_bwd_desc_t* bd, void* stream_)
     return launch_fused_recompute(d, fb, fo, fn, (hipStream_t)stream_);
   }
   if (bd->act_given && bwd_col16_supported(d)) return launch_bwd_col16(*bd, (hipStream_t)stream_);  // small batches, saved activations
+  if (bd->act_given && bwd_col16_persist_supported(d)) return launch_bwd_col16_persist(*bd, (hipStream_t)stream_);  // large batches at 128 features
   GNC_REQUIRE(!bd->grad_gather, "gnc_mlp_backward_f32: grad_gather is only honoured by the fused data + weight-gradient kernel");
   const bool resident = bwd_shape(d, &nmm, &nadd, &T);
   const bool saved = bd->act_given != 0;
@@ -1364,6 +1365,7 @@ extern "C" int gnc_mlp_backward_saved_act_honoured(const gnc_mlp_bwd_desc_t* bd)
     if (!bd->act[l] || !fused_al16(bd->act[l]) || d.out_dim[l] % 4 != 0) return 0;
   if (bd->dw_partial[0]) return fused_shape(d) >= 0 ? 1 : 0;  // fused data + weight-gradient kernel (widths <= 64)
   if (d.num_linear >= 2 && bwd_col16_supported(d)) return 1;     // small batches: the column-split data kernel
+  if (bwd_col16_persist_supported(d)) return 1;
   // split path: the streaming kernels read them (and gnc_xty_f32 after them); the weights-resident data kernel recomputes
   int nmm, nadd, T;
   BwdPlan pl;
@@ -1379,7 +1381,7 @@ extern "C" int gnc_mlp_backward_grad_gather_honoured(const gnc_mlp_bwd_desc_t* b
   static const bool off = getenv("GNC_NO_GRAD_GATHER_FOLD") != nullptr;  // A/B switch: the caller gathers the rows itself
   if (off || !bd || !bd->grad_gather || !bd->grad_gather_index) return 0;
   if (!bd->dw_partial[0]) {  // split path: only the small-batch data kernel (saved activations) gathers in the launch
-    return (bd->act_given && gnc_mlp::validate_desc(&bd->fwd, false) == GNC_OK && bwd_col16_supported(bd->fwd) &&
+    return (bd->act_given && gnc_mlp::validate_desc(&bd->fwd, false) == GNC_OK && (bwd_col16_supported(bd->fwd) || bwd_col16_persist_supported(bd->fwd)) &&
             bd->ld_grad_gather % 4 == 0 && fused_al16(bd->grad_gather) && bd->ld_grad_gather >= bd->fwd.out_dim[bd->fwd.num_linear - 1])
                ? 1 : 0;
   }
@@ -1407,6 +1409,7 @@ extern "C" int gnc_mlp_backward_ln_partial_rows(const gnc_mlp_desc_t* fwd) {
   // backward descriptions carry the forward's saved post-activations in fwd.save_act too (same pointers as act[]): with
   // them a small batch runs the column-split data kernel, one partial row per 16-row tile
   if (fwd->save_act[0] && fwd->num_linear >= 2 && bwd_col16_supported(*fwd)) return bwd_col16_ln_partial_rows(fwd->rows);
+  if (fwd->save_act[0] && bwd_col16_persist_supported(*fwd)) return bwd_col16_persist_ln_partial_rows(fwd->rows);
   int nmm = 0, nadd = 0, T = 0;
   if (bwd_shape(*fwd, &nmm, &nadd, &T)) return bwd_grid(fwd->rows) * BWAVES;
   if (off) return 0;

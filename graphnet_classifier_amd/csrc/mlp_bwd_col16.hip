@@ -303,6 +303,221 @@ __global__ __launch_bounds__(NT * 64) void mlp_bwd_col16_kernel(const BPlan p) {
   }
 }
 
+// ---- large batches at exactly 128 features (the c2 configuration): the same tile program with the weights RESIDENT IN
+// REGISTERS.  One 8-wave workgroup per CU walks its tiles; W_2 (both as the forward reads it and transposed), W_1^T and the
+// dx chunk of W_0^T are loaded once (4 x 32 registers per lane), the rows of the NEXT tile (grad_out, the saved activations,
+// the gather id) are requested while the current one is computed, and a tile's last result (dx) is stored from the top of the
+// next tile, so that the wait for the prefetched rows does not sit behind fresh stores.  Per tile nothing but its rows moves:
+// 16 x 128 x (g, a_0, a_1 in; dz_2, dz_1, dz_0, dx out).  LayerNorm parameter sums: one partial row per workgroup.
+// Shape (checked by bwd_col16_persist_supported): 3 Linears, hidden = out = 128, LayerNorm, saved activations, in_dim[0] = 128
+// when dx is wanted.
+template <int N0, bool GG>
+__global__ __launch_bounds__(512) void mlp_bwd_col16_persist_kernel(const BPlan p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int NT = 8, D = 128;
+  constexpr int LDH = NT * 16 + 4;
+  constexpr int CPP = 32;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  const int f0 = 16 * w + 4 * g;
+  const int sr = tid / CPP, sc4 = tid % CPP;
+  const int rows = p.rows;
+  float* hbuf = lds;
+  float* abuf = hbuf + 2 * 16 * LDH;
+  float* lnbuf = abuf + 16 * LDH;
+
+  auto wload_fw = [&](f32x4 (&wr)[NKB], const BChunk& c) {
+    const __amdgpu_buffer_rsrc_t win = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(c.w), 0, c.nrec, 0x00020000);
+    const uint32_t off0 = (uint32_t)((16 * w + j) * c.ldw + 4 * g) * 4u;
+#pragma unroll
+    for (int cb = 0; cb < NKB; ++cb) wr[cb] = window_load(win, off0 + (uint32_t)(cb * 64));
+  };
+  auto wload_tr = [&](f32x4 (&wr)[NKB], const BChunk& c) {
+    const __amdgpu_buffer_rsrc_t win = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(c.w), 0, c.nrec, 0x00020000);
+    const uint32_t off0 = (uint32_t)(4 * g * c.ldw + 16 * w + j) * 4u;
+    const uint32_t rowb = (uint32_t)c.ldw * 4u;
+#pragma unroll
+    for (int cb = 0; cb < NKB; ++cb) {
+      const uint32_t so = (uint32_t)(16 * cb) * rowb;
+      wr[cb].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(win, off0, so, 0));
+      wr[cb].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(win, off0, so + rowb, 0));
+      wr[cb].z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(win, off0, so + 2 * rowb, 0));
+      wr[cb].w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(win, off0, so + 3 * rowb, 0));
+    }
+  };
+  auto mma = [&](f32x4& acc0, f32x4& acc1, const f32x4 (&wr)[NKB], const float* src) {
+#pragma unroll
+    for (int c0 = 0; c0 < NKB; c0 += 4) {
+      f32x4 b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) b[u] = *reinterpret_cast<const f32x4*>(src + 16 * (c0 + u));
+#pragma unroll
+      for (int u = 0; u < 4; u += 2) {
+        acc0 = mfma16(wr[c0 + u].x, b[u].x, acc0);
+        acc1 = mfma16(wr[c0 + u + 1].x, b[u + 1].x, acc1);
+        acc0 = mfma16(wr[c0 + u].y, b[u].y, acc0);
+        acc1 = mfma16(wr[c0 + u + 1].y, b[u + 1].y, acc1);
+        acc0 = mfma16(wr[c0 + u].z, b[u].z, acc0);
+        acc1 = mfma16(wr[c0 + u + 1].z, b[u + 1].z, acc1);
+        acc0 = mfma16(wr[c0 + u].w, b[u].w, acc0);
+        acc1 = mfma16(wr[c0 + u + 1].w, b[u + 1].w, acc1);
+      }
+    }
+  };
+  auto sum_rows = [&](float x) -> float {
+    x += __shfl_xor(x, 8, 64);
+    x += __shfl_xor(x, 4, 64);
+    x += __shfl_xor(x, 2, 64);
+    x += __shfl_xor(x, 1, 64);
+    return x;
+  };
+
+  f32x4 wfw[NKB], wt0[NKB], wt1[NKB], wdx[N0 ? NKB : 1];
+  wload_fw(wfw, p.fw);
+  wload_tr(wt0, p.tr[0]);
+  wload_tr(wt1, p.tr[1]);
+  if constexpr (N0 > 0) wload_tr(wdx, p.tr[2]);
+  const f32x4 gamma4 = *reinterpret_cast<const f32x4*>(p.gamma + f0);
+  const f32x4 bias4 = p.bias_last ? *reinterpret_cast<const f32x4*>(p.bias_last + f0) : f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 sum_b = {0.f, 0.f, 0.f, 0.f}, sum_g = {0.f, 0.f, 0.f, 0.f};
+
+  // rows of a tile, requested one tile ahead
+  f32x4 r_gv = {0.f, 0.f, 0.f, 0.f}, r_gg = {0.f, 0.f, 0.f, 0.f}, r_sa, r_a0, r_a1;
+  int r_gid = 0;
+  auto request_rows = [&](int tt) {
+    const int r0 = tt * R16;
+    const int mr = r0 + j < rows ? r0 + j : rows - 1;
+    const int sw = r0 + sr < rows ? r0 + sr : rows - 1;
+    if constexpr (GG) r_gid = p.gg_index[mr];
+    if (p.has_g) r_gv = *reinterpret_cast<const f32x4*>(p.grad_out + (int64_t)mr * p.ld_g + f0);
+    r_sa = *reinterpret_cast<const f32x4*>(p.act[1] + (int64_t)sw * D + sc4 * 4);
+    r_a0 = *reinterpret_cast<const f32x4*>(p.act[0] + (int64_t)mr * D + f0);
+    r_a1 = *reinterpret_cast<const f32x4*>(p.act[1] + (int64_t)mr * D + f0);
+  };
+  auto request_gather = [&]() {
+    if constexpr (GG) {
+      const bool ok = (uint32_t)r_gid < p.gg_rows;
+      r_gg = *reinterpret_cast<const f32x4*>(p.gg + (int64_t)(ok ? r_gid : 0) * p.ld_gg + f0);
+      r_gg = ok ? r_gg : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  int t = blockIdx.x;
+  request_rows(t);
+  request_gather();
+  f32x4 dx_pending = {0.f, 0.f, 0.f, 0.f};
+  int dx_row = -1;  // row of dx_pending (-1: nothing pending)
+
+  for (; t < p.num_tiles; t += gridDim.x) {
+    const int row0 = t * R16;
+    const bool row_live = row0 + j < rows;
+    // ---- this tile's rows leave the prefetch registers; the next tile's are requested
+    f32x4 gv = r_gv + r_gg;
+    if (!row_live) gv = f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 a0 = r_a0, a1 = r_a1;
+    *reinterpret_cast<f32x4*>(abuf + sr * LDH + sc4 * 4) = r_sa;
+    if constexpr (N0 > 0) {
+      if (dx_row >= 0) *reinterpret_cast<f32x4*>(p.dx + (int64_t)dx_row * p.ld_dx + f0) = dx_pending;
+    }
+    const int tn = t + (int)gridDim.x < p.num_tiles ? t + (int)gridDim.x : p.num_tiles - 1;
+    request_rows(tn);
+    __syncthreads();
+
+    // ---- LayerNorm statistics from the recomputed last pre-activation, LayerNorm backward
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    mma(acc0, acc1, wfw, abuf + j * LDH + 4 * g);
+    f32x4 z = (acc0 + acc1) + bias4;
+    constexpr float inv_n = 1.f / (float)D;
+    float s = add_quarters((z.x + z.y) + (z.z + z.w));
+    if (g == 0) lnbuf[w * 16 + j] = s;
+    __syncthreads();
+    s = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < NT; ++ww) s += lnbuf[ww * 16 + j];
+    const float mean = s * inv_n;
+    z -= f32x4{mean, mean, mean, mean};
+    float v = add_quarters((z.x * z.x + z.y * z.y) + (z.z * z.z + z.w * z.w));
+    if (g == 0) lnbuf[NT * 16 + w * 16 + j] = v;
+    __syncthreads();
+    v = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < NT; ++ww) v += lnbuf[NT * 16 + ww * 16 + j];
+    const float rstd = __frsqrt_rn(v * inv_n + p.eps);
+    const f32x4 yh = z * rstd;
+    sum_b += gv;
+    sum_g += gv * yh;
+    const f32x4 dy = gv * gamma4;
+    float s1 = add_quarters((dy.x + dy.y) + (dy.z + dy.w));
+    float s2 = add_quarters((dy.x * yh.x + dy.y * yh.y) + (dy.z * yh.z + dy.w * yh.w));
+    if (g == 0) {
+      lnbuf[2 * NT * 16 + w * 16 + j] = s1;
+      lnbuf[3 * NT * 16 + w * 16 + j] = s2;
+    }
+    __syncthreads();
+    s1 = 0.f;
+    s2 = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < NT; ++ww) {
+      s1 += lnbuf[2 * NT * 16 + ww * 16 + j];
+      s2 += lnbuf[3 * NT * 16 + ww * 16 + j];
+    }
+    const float m1 = s1 * inv_n, m2 = s2 * inv_n;
+    f32x4 dz = (dy - f32x4{m1, m1, m1, m1} - yh * m2) * rstd;
+    request_gather();  // the next tile's gathered rows: its ids have landed by now
+    if (row_live) *reinterpret_cast<f32x4*>(p.dz[2] + (int64_t)(row0 + j) * D + f0) = dz;
+
+    // ---- dz_1 = (dz_2 W_2) * [a_1 > 0], dz_0 = (dz_1 W_1) * [a_0 > 0]
+    *reinterpret_cast<f32x4*>(hbuf + j * LDH + f0) = dz;
+    __syncthreads();
+    acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    mma(acc0, acc1, wt0, hbuf + j * LDH + 4 * g);
+    dz = acc0 + acc1;
+    dz.x = a1.x > 0.f ? dz.x : 0.f; dz.y = a1.y > 0.f ? dz.y : 0.f; dz.z = a1.z > 0.f ? dz.z : 0.f; dz.w = a1.w > 0.f ? dz.w : 0.f;
+    if (row_live) *reinterpret_cast<f32x4*>(p.dz[1] + (int64_t)(row0 + j) * D + f0) = dz;
+    float* hb1 = hbuf + 16 * LDH;
+    *reinterpret_cast<f32x4*>(hb1 + j * LDH + f0) = dz;
+    __syncthreads();
+    acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    mma(acc0, acc1, wt1, hb1 + j * LDH + 4 * g);
+    dz = acc0 + acc1;
+    dz.x = a0.x > 0.f ? dz.x : 0.f; dz.y = a0.y > 0.f ? dz.y : 0.f; dz.z = a0.z > 0.f ? dz.z : 0.f; dz.w = a0.w > 0.f ? dz.w : 0.f;
+    if (row_live) *reinterpret_cast<f32x4*>(p.dz[0] + (int64_t)(row0 + j) * D + f0) = dz;
+
+    // ---- dx = dz_0 W_0 (+ g: the residual's gradient); stored from the top of the next tile
+    if constexpr (N0 > 0) {
+      *reinterpret_cast<f32x4*>(hbuf + j * LDH + f0) = dz;  // buffer 0: its readers passed the barrier above
+      __syncthreads();
+      acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
+      acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+      mma(acc0, acc1, wdx, hbuf + j * LDH + 4 * g);
+      dx_pending = acc0 + acc1;
+      if (p.dx_add_chunk == 0) dx_pending += gv;
+      dx_row = row_live ? row0 + j : -1;
+    }
+    __syncthreads();  // abuf / hbuf are rewritten at the top of the next tile
+  }
+  if constexpr (N0 > 0) {
+    if (dx_row >= 0) *reinterpret_cast<f32x4*>(p.dx + (int64_t)dx_row * p.ld_dx + f0) = dx_pending;
+  }
+  // ---- d beta / d gamma: this workgroup's partial row
+  f32x4 sb, sg;
+  sb.x = sum_rows(sum_b.x); sb.y = sum_rows(sum_b.y); sb.z = sum_rows(sum_b.z); sb.w = sum_rows(sum_b.w);
+  sg.x = sum_rows(sum_g.x); sg.y = sum_rows(sum_g.y); sg.z = sum_rows(sum_g.z); sg.w = sum_rows(sum_g.w);
+  if (j == 0) {
+    float* lp = p.ln_partial + (int64_t)blockIdx.x * 2 * D;
+    *reinterpret_cast<f32x4*>(lp + f0) = sb;
+    *reinterpret_cast<f32x4*>(lp + D + f0) = sg;
+  }
+}
+
+int persist_grid(int64_t rows) {
+  const int64_t tiles = gnc::ceil_div(rows, (int64_t)R16);
+  return (int)(tiles < gnc::num_cu() ? tiles : gnc::num_cu());
+}
+
 template <int NT>
 int launch_b(const BPlan& p, hipStream_t stream) {
   const size_t smem = ((size_t)3 * 16 * (NT * 16 + 4) + 4 * NT * 16) * sizeof(float);
@@ -348,6 +563,83 @@ bool gnc_mlp::bwd_col16_supported(const gnc_mlp_desc_t& d) {
 }
 
 int gnc_mlp::bwd_col16_ln_partial_rows(int64_t rows) { return (int)gnc::ceil_div(rows, (int64_t)R16); }
+
+// Large batches at exactly 128 features with saved activations (the c2 training configuration's edge processors): the
+// register-resident variant.  Shape fields and alignment only.
+bool gnc_mlp::bwd_col16_persist_supported(const gnc_mlp_desc_t& d) {
+  static const bool off = getenv("GNC_NO_BWD_PERSIST") != nullptr;  // A/B switch: the 32-row streamed kernel
+  if (off || d.rows <= col16_max_rows() || d.rows >= INT32_MAX / 2) return false;
+  if (d.num_linear != 3 || !d.ln_gamma || !d.ln_beta) return false;
+  for (int l = 0; l < 3; ++l)
+    if (d.out_dim[l] != 128 || (l > 0 && d.in_dim[l] != 128) || ldw_of(d, l) % 4 != 0 || !al16b(d.weight[l]) ||
+        (int64_t)128 * ldw_of(d, l) * 4 > 0x7fffffffll)
+      return false;
+  if (d.in_dim[0] != 128 || !al16b(d.ln_gamma) || (d.bias[2] && !al16b(d.bias[2]))) return false;
+  int nmm = 0;
+  for (int s = 0; s < d.num_segments; ++s) {
+    if (d.seg[s].mode != GNC_SEG_MATMUL) continue;
+    ++nmm;
+    if (d.seg[s].index || d.seg[s].width != 128 || d.seg[s].wcol != 0) return false;
+  }
+  return nmm == 1;
+}
+int gnc_mlp::bwd_col16_persist_ln_partial_rows(int64_t rows) { return persist_grid(rows); }
+
+int gnc_mlp::launch_bwd_col16_persist(const gnc_mlp_bwd_desc_t& bd, hipStream_t stream) {
+  const gnc_mlp_desc_t& d = bd.fwd;
+  constexpr int D = 128;
+  GNC_REQUIRE(bd.grad_out || bd.grad_gather, "gnc_mlp_backward_f32: grad_out is null");
+  GNC_REQUIRE(!bd.grad_out || (bd.ld_grad_out % 4 == 0 && al16b(bd.grad_out) && bd.ld_grad_out >= D),
+              "gnc_mlp_backward_f32: grad_out must be 16-B aligned with ld %% 4 == 0");
+  GNC_REQUIRE(!bd.grad_gather || (bd.ld_grad_gather % 4 == 0 && al16b(bd.grad_gather) && bd.grad_gather_index && bd.ld_grad_gather >= D),
+              "gnc_mlp_backward_f32: grad_gather must be 16-B aligned with ld %% 4 == 0");
+  GNC_REQUIRE(bd.ln_partial && al16b(bd.ln_partial), "gnc_mlp_backward_f32: ln_partial is required (gnc_mlp_backward_ln_partial_rows rows)");
+  GNC_REQUIRE(!bd.dx || (bd.ld_dx % 4 == 0 && al16b(bd.dx) && bd.ld_dx >= D), "gnc_mlp_backward_f32: dx must be 16-B aligned with ld %% 4 == 0");
+  BPlan p = {};
+  p.rows = (int)d.rows;
+  p.num_tiles = (int)gnc::ceil_div(d.rows, (int64_t)R16);
+  p.L = 3; p.H = D; p.od = D;
+  p.n0 = bd.dx ? 1 : 0;
+  p.k_in = D;
+  p.has_ln = 1;
+  p.has_g = bd.grad_out ? 1 : 0;
+  p.has_gg = bd.grad_gather ? 1 : 0;
+  for (int l = 0; l < 3; ++l) {
+    GNC_REQUIRE(bd.dz[l] && al16b(bd.dz[l]), "gnc_mlp_backward_f32: dz[%d] must be given, 16-B aligned", l);
+    p.dz[l] = bd.dz[l];
+    if (l < 2) {
+      GNC_REQUIRE(bd.act[l] && al16b(bd.act[l]), "gnc_mlp_backward_f32: act[%d] must be given, 16-B aligned", l);
+      p.act[l] = bd.act[l];
+    }
+  }
+  p.fw = {d.weight[2], ldw_of(d, 2), (127 * ldw_of(d, 2) + D) * 4, D};
+  p.tr[0] = {d.weight[2], ldw_of(d, 2), (127 * ldw_of(d, 2) + D) * 4, D};
+  p.tr[1] = {d.weight[1], ldw_of(d, 1), (127 * ldw_of(d, 1) + D) * 4, D};
+  p.tr[2] = {d.weight[0], ldw_of(d, 0), (127 * ldw_of(d, 0) + D) * 4, D};
+  p.bias_last = d.bias[2];
+  p.gamma = d.ln_gamma;
+  p.eps = d.ln_eps;
+  p.grad_out = bd.grad_out;
+  p.ld_g = bd.ld_grad_out;
+  p.gg = bd.grad_gather;
+  p.ld_gg = bd.ld_grad_gather;
+  p.gg_index = bd.grad_gather_index;
+  p.gg_rows = bd.grad_gather_rows > INT32_MAX ? (uint32_t)INT32_MAX : (uint32_t)bd.grad_gather_rows;
+  p.dx = bd.dx;
+  p.ld_dx = bd.ld_dx;
+  p.dx_add_chunk = (bd.dx && bd.dx_add_grad_out) ? 0 : -1;
+  p.ln_partial = bd.ln_partial;
+  const size_t smem = ((size_t)3 * 16 * (8 * 16 + 4) + 4 * 8 * 16) * sizeof(float);
+  const dim3 grid((unsigned)persist_grid(d.rows)), block(512);
+  if (bd.dx) {
+    if (bd.grad_gather) mlp_bwd_col16_persist_kernel<1, true><<<grid, block, smem, stream>>>(p);
+    else mlp_bwd_col16_persist_kernel<1, false><<<grid, block, smem, stream>>>(p);
+  } else {
+    if (bd.grad_gather) mlp_bwd_col16_persist_kernel<0, true><<<grid, block, smem, stream>>>(p);
+    else mlp_bwd_col16_persist_kernel<0, false><<<grid, block, smem, stream>>>(p);
+  }
+  return gnc::check_launch("mlp_bwd_col16_persist_kernel");
+}
 
 int gnc_mlp::launch_bwd_col16(const gnc_mlp_bwd_desc_t& bd, hipStream_t stream) {
   const gnc_mlp_desc_t& d = bd.fwd;

@@ -782,6 +782,10 @@ int64_t col16_max_rows();
 bool bwd_col16_supported(const gnc_mlp_desc_t& d);
 int bwd_col16_ln_partial_rows(int64_t rows);
 int launch_bwd_col16(const gnc_mlp_bwd_desc_t& bd, hipStream_t stream);
+// ... and its register-resident variant for large batches at exactly 128 features (3 Linears, LayerNorm, one row-ordered table)
+bool bwd_col16_persist_supported(const gnc_mlp_desc_t& d);
+int bwd_col16_persist_ln_partial_rows(int64_t rows);
+int launch_bwd_col16_persist(const gnc_mlp_bwd_desc_t& bd, hipStream_t stream);
 // K8 data kernel for widths 129..256 on 16-row tiles (mlp_backward16.hip): shape query / launch
 bool bwd_stream16_supported(const gnc_mlp_desc_t& d, bool want_dx);
 int bwd_stream16_ln_partial_rows(int64_t rows);
