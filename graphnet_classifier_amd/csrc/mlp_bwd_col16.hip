@@ -408,6 +408,18 @@ __global__ __launch_bounds__(512) void mlp_bwd_col16_persist_kernel(const BPlan 
   request_gather();
   f32x4 dx_pending = {0.f, 0.f, 0.f, 0.f};
   int dx_row = -1;  // row of dx_pending (-1: nothing pending)
+  auto store_dx = [&]() {  // (in_dim[0] <= 128 columns; rows of 16-B pieces when vec_dx)
+    if (dx_row < 0 || f0 >= p.k_in) return;
+    float* op = p.dx + (int64_t)dx_row * p.ld_dx + f0;
+    if (p.vec_dx) {
+      *reinterpret_cast<f32x4*>(op) = dx_pending;
+    } else {
+      op[0] = dx_pending.x;
+      if (f0 + 1 < p.k_in) op[1] = dx_pending.y;
+      if (f0 + 2 < p.k_in) op[2] = dx_pending.z;
+      if (f0 + 3 < p.k_in) op[3] = dx_pending.w;
+    }
+  };
 
   for (; t < p.num_tiles; t += gridDim.x) {
     const int row0 = t * R16;
@@ -417,9 +429,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_col16_persist_kernel(const BPlan 
     if (!row_live) gv = f32x4{0.f, 0.f, 0.f, 0.f};
     const f32x4 a0 = r_a0, a1 = r_a1;
     *reinterpret_cast<f32x4*>(abuf + sr * LDH + sc4 * 4) = r_sa;
-    if constexpr (N0 > 0) {
-      if (dx_row >= 0) *reinterpret_cast<f32x4*>(p.dx + (int64_t)dx_row * p.ld_dx + f0) = dx_pending;
-    }
+    if constexpr (N0 > 0) store_dx();
     const int tn = t + (int)gridDim.x < p.num_tiles ? t + (int)gridDim.x : p.num_tiles - 1;
     request_rows(tn);
     __syncthreads();
@@ -499,9 +509,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_col16_persist_kernel(const BPlan 
     }
     __syncthreads();  // abuf / hbuf are rewritten at the top of the next tile
   }
-  if constexpr (N0 > 0) {
-    if (dx_row >= 0) *reinterpret_cast<f32x4*>(p.dx + (int64_t)dx_row * p.ld_dx + f0) = dx_pending;
-  }
+  if constexpr (N0 > 0) store_dx();
   // ---- d beta / d gamma: this workgroup's partial row
   f32x4 sb, sg;
   sb.x = sum_rows(sum_b.x); sb.y = sum_rows(sum_b.y); sb.z = sum_rows(sum_b.z); sb.w = sum_rows(sum_b.w);
@@ -571,17 +579,15 @@ bool gnc_mlp::bwd_col16_persist_supported(const gnc_mlp_desc_t& d) {
   if (off || d.rows <= col16_max_rows() || d.rows >= INT32_MAX / 2) return false;
   if (d.num_linear != 3 || !d.ln_gamma || !d.ln_beta) return false;
   for (int l = 0; l < 3; ++l)
-    if (d.out_dim[l] != 128 || (l > 0 && d.in_dim[l] != 128) || ldw_of(d, l) % 4 != 0 || !al16b(d.weight[l]) ||
+    if (d.out_dim[l] != 128 || (l > 0 && d.in_dim[l] != 128) || (l == 2 && (ldw_of(d, l) % 4 != 0 || !al16b(d.weight[l]))) ||
         (int64_t)128 * ldw_of(d, l) * 4 > 0x7fffffffll)
       return false;
-  if (d.in_dim[0] != 128 || !al16b(d.ln_gamma) || (d.bias[2] && !al16b(d.bias[2]))) return false;
-  int nmm = 0;
-  for (int s = 0; s < d.num_segments; ++s) {
-    if (d.seg[s].mode != GNC_SEG_MATMUL) continue;
-    ++nmm;
-    if (d.seg[s].index || d.seg[s].width != 128 || d.seg[s].wcol != 0) return false;
-  }
-  return nmm == 1;
+  if (d.in_dim[0] > 128 || !al16b(d.ln_gamma) || (d.bias[2] && !al16b(d.bias[2]))) return false;
+  const int lm = last_matmul(d);
+  if (lm < 0) return false;
+  // a residual's gradient is folded into dx only as the whole (one) chunk
+  if (!d.seg[lm].index && d.seg[lm].width == 128 && d.seg[lm].wcol != 0) return false;
+  return true;
 }
 int gnc_mlp::bwd_col16_persist_ln_partial_rows(int64_t rows) { return persist_grid(rows); }
 
@@ -594,13 +600,14 @@ int gnc_mlp::launch_bwd_col16_persist(const gnc_mlp_bwd_desc_t& bd, hipStream_t 
   GNC_REQUIRE(!bd.grad_gather || (bd.ld_grad_gather % 4 == 0 && al16b(bd.grad_gather) && bd.grad_gather_index && bd.ld_grad_gather >= D),
               "gnc_mlp_backward_f32: grad_gather must be 16-B aligned with ld %% 4 == 0");
   GNC_REQUIRE(bd.ln_partial && al16b(bd.ln_partial), "gnc_mlp_backward_f32: ln_partial is required (gnc_mlp_backward_ln_partial_rows rows)");
-  GNC_REQUIRE(!bd.dx || (bd.ld_dx % 4 == 0 && al16b(bd.dx) && bd.ld_dx >= D), "gnc_mlp_backward_f32: dx must be 16-B aligned with ld %% 4 == 0");
+  GNC_REQUIRE(!bd.dx || bd.ld_dx >= d.in_dim[0], "gnc_mlp_backward_f32: ld_dx < in_dim[0]");
   BPlan p = {};
   p.rows = (int)d.rows;
   p.num_tiles = (int)gnc::ceil_div(d.rows, (int64_t)R16);
   p.L = 3; p.H = D; p.od = D;
   p.n0 = bd.dx ? 1 : 0;
-  p.k_in = D;
+  p.k_in = d.in_dim[0];
+  p.vec_dx = (bd.dx && bd.ld_dx % 4 == 0 && d.in_dim[0] % 4 == 0 && al16b(bd.dx)) ? 1 : 0;
   p.has_ln = 1;
   p.has_g = bd.grad_out ? 1 : 0;
   p.has_gg = bd.grad_gather ? 1 : 0;
@@ -615,7 +622,7 @@ int gnc_mlp::launch_bwd_col16_persist(const gnc_mlp_bwd_desc_t& bd, hipStream_t 
   p.fw = {d.weight[2], ldw_of(d, 2), (127 * ldw_of(d, 2) + D) * 4, D};
   p.tr[0] = {d.weight[2], ldw_of(d, 2), (127 * ldw_of(d, 2) + D) * 4, D};
   p.tr[1] = {d.weight[1], ldw_of(d, 1), (127 * ldw_of(d, 1) + D) * 4, D};
-  p.tr[2] = {d.weight[0], ldw_of(d, 0), (127 * ldw_of(d, 0) + D) * 4, D};
+  p.tr[2] = {d.weight[0], ldw_of(d, 0), (127 * ldw_of(d, 0) + d.in_dim[0]) * 4, D};
   p.bias_last = d.bias[2];
   p.gamma = d.ln_gamma;
   p.eps = d.ln_eps;
@@ -628,6 +635,11 @@ int gnc_mlp::launch_bwd_col16_persist(const gnc_mlp_bwd_desc_t& bd, hipStream_t 
   p.dx = bd.dx;
   p.ld_dx = bd.ld_dx;
   p.dx_add_chunk = (bd.dx && bd.dx_add_grad_out) ? 0 : -1;
+  if (p.dx_add_chunk == 0) {
+    const int lm = last_matmul(d);
+    GNC_REQUIRE(lm >= 0 && d.seg[lm].width == D && !d.seg[lm].index && d.seg[lm].wcol == 0 && d.in_dim[0] == D,
+                "gnc_mlp_backward_f32: dx_add_grad_out needs one row-ordered MATMUL segment as wide as the output");
+  }
   p.ln_partial = bd.ln_partial;
   const size_t smem = ((size_t)3 * 16 * (8 * 16 + 4) + 4 * 8 * 16) * sizeof(float);
   const dim3 grid((unsigned)persist_grid(d.rows)), block(512);
