@@ -17,9 +17,8 @@
 // A launch of this kernel is a few microseconds long, so its INSTRUCTION COUNT in front of the first MFMA is what it costs:
 // the launcher digests the generic description into a ColPlan (per weight chunk: pointer, stride, window; per staging pass:
 // the one segment that covers it; ...) and the kernel never looks at gnc_mlp_desc_t.
-// Aggregation epilogue (AGG): the finished rows go through the idle hidden tile and `out_dim` lanes walk the 16 rows in order
-// (bit-identical to K1: sums start at 0.0 and add rows in ascending order); the first / last destination of a tile are left
-// to gnc_agg_fixup_f32 when the neighbouring tile holds more of their rows (agg_fix[2 tile], [2 tile + 1]; -1 otherwise).
+// No aggregation epilogue here: at this size the fix-up and zero-fill launches the epilogue needs cost more than K1 itself
+// (scatter_sum_csr_small: 4.8 us), so gnc_mlp_agg_supported() says no for these launches and the caller runs K1 on the rows.
 // Rounding differs from the streaming kernels (two interleaved accumulators per output tile): callers compare with
 // tolerances, not bit for bit, across kernel families.
 #include <stdlib.h>
@@ -71,7 +70,7 @@ struct ColPlan {
   int narrow_w0;     // weight[0] is read by dwords (in_dim[0] <= 16, rows not made of 16-B pieces)
   int nrec_narrow;   // ... through a window of this many bytes (ch[0].nrec is 0 then: the 16-B loads of set 0 read nothing)
   int vec_stage;     // every MATMUL segment is made of 16-B pieces and every staging pass lies inside one segment
-  int fix_len, nadd, nseg;
+  int nadd, nseg;
   int res_xcol;      // >= 0: the residual is this column block of the staged input tile
   int vec_out;       // output rows are 16-B pieces
   int out_dim[NQ], in_dim[NQ];
@@ -88,10 +87,6 @@ struct ColPlan {
   float* out;
   int ld_out;
   float* save[NQ];
-  float* agg_out;
-  int ld_agg;
-  const int32_t* agg_index;
-  int32_t* agg_fix;
 };
 
 // Shape traits: what the launcher knows about a launch at compile time.  A launch of this kernel is a few microseconds long
@@ -139,7 +134,7 @@ extern "C" int gnc_col_probe_read(void* dst, size_t bytes) {
 #define CPROBE(k) do {} while (0)
 #endif
 
-template <int NT, bool AGG, bool SAVE, bool IDX, class S = ShapeAny>
+template <int NT, bool SAVE, bool IDX, class S = ShapeAny>
 __global__ __launch_bounds__(NT * 64) void mlp_col16_kernel(const ColPlan p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int NTV = NT * 64;
@@ -161,7 +156,6 @@ __global__ __launch_bounds__(NT * 64) void mlp_col16_kernel(const ColPlan p) {
   float* xbuf = lds;                                    // [16][ldx]: the first Linear's input rows (virtual concat)
   float* hbuf = xbuf + 16 * ldx;                        // [2][16][LDH]: hidden rows, ping-pong
   float* lnbuf = hbuf + 2 * 16 * LDH;                   // [2][NT][16]: per-wave row sums of the LayerNorm
-  int* idbuf0 = reinterpret_cast<int*>(lnbuf + 2 * NT * 16);  // [2][18]: destination of row0 - 1, the tile's rows, row0 + 16
 #ifdef GNC_PHASE_PROBE
   const unsigned long long probe_t0 = __builtin_readcyclecounter();
 #endif
@@ -171,9 +165,6 @@ __global__ __launch_bounds__(NT * 64) void mlp_col16_kernel(const ColPlan p) {
       const int r = u / padw, c = u - r * padw;
       xbuf[r * ldx + p.k_in + c] = 0.f;
     }
-  }
-  if constexpr (AGG) {
-    for (int e = 2 * p.num_tiles + (int)blockIdx.x * NTV + tid0; e < p.fix_len; e += (int)gridDim.x * NTV) p.agg_fix[e] = -1;
   }
 
   // Weight rows [16w, 16w + 16) of a chunk through a bounds-checked window that ends with the matrix (rows past it read as
@@ -245,7 +236,6 @@ __global__ __launch_bounds__(NT * 64) void mlp_col16_kernel(const ColPlan p) {
 
   int it = 0;
   for (int t = blockIdx.x; t < p.num_tiles; t += gridDim.x, ++it) {
-    int* idbuf = idbuf0 + (it & 1) * 18;  // by tile parity: the walkers of the previous tile may still be reading theirs
 #ifdef GNC_PHASE_PROBE
     if (blockIdx.x < 1024 && it == 0 && (threadIdx.x & 63) == 0) gnc_col_probe[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 12] = probe_t0;
 #endif
@@ -288,13 +278,6 @@ __global__ __launch_bounds__(NT * 64) void mlp_col16_kernel(const ColPlan p) {
         id_row[s] = (ip ? ip : reinterpret_cast<const int32_t*>(gnc_col_dummy))[ip ? srow : 0];
         id_row[s] = ip ? id_row[s] : srow;
       }
-    }
-    int agg_id = -1;
-    if constexpr (AGG) {
-      const int e = row0 - 1 + (tid < 18 ? tid : 0);
-      const bool in = e >= 0 && e < rows;
-      agg_id = p.agg_index[in ? e : 0];
-      agg_id = in ? agg_id : -1;
     }
 
     // chunk q of the tile: q < n0: columns [q CK, ..) of the first Linear; else Linear q - n0 + 1 (widths <= 128: one chunk)
@@ -387,9 +370,6 @@ __global__ __launch_bounds__(NT * 64) void mlp_col16_kernel(const ColPlan p) {
           }
         }
       }
-    }
-    if constexpr (AGG) {
-      if (tid < 18) idbuf[tid] = agg_id;
     }
     CPROBE(2);  // rows staged (ids, rows waited for)
     __syncthreads();
@@ -485,45 +465,16 @@ __global__ __launch_bounds__(NT * 64) void mlp_col16_kernel(const ColPlan p) {
     }
 
     CPROBE(7);  // rows stored
-    if constexpr (AGG) {
-      float* ob = hbuf + ((L - 1) & 1) * 16 * LDH;  // idle since the previous layer but one
-      *reinterpret_cast<f32x4*>(ob + j * LDH + f0) = o;
-      __syncthreads();
-      if (tid < od) {
-        const int valid = rows - row0 < R16 ? rows - row0 : R16;
-        const int first = idbuf[1];
-        const bool cut_first = idbuf[0] == first;
-        float acc = 0.f;
-        int cur = first;
-        bool cur_is_first = true;
-        for (int r = 0; r < valid; ++r) {
-          const int id = idbuf[1 + r];
-          if (id != cur) {
-            if (!(cur_is_first && cut_first)) p.agg_out[(int64_t)cur * p.ld_agg + tid] = acc;
-            cur = id;
-            cur_is_first = false;
-            acc = 0.f;
-          }
-          acc += ob[r * LDH + tid];
-        }
-        const bool cut_last = idbuf[1 + valid] == cur;
-        if (!cut_last && !(cur_is_first && cut_first)) p.agg_out[(int64_t)cur * p.ld_agg + tid] = acc;
-        if (tid == 0) {
-          p.agg_fix[2 * t] = cut_first ? first : -1;
-          p.agg_fix[2 * t + 1] = cut_last ? cur : -1;
-        }
-      }
-    }
     CPROBE(8);
   }
 }
 
-template <int NT, bool AGG, bool SAVE, bool IDX, class S = ShapeAny>
+template <int NT, bool SAVE, bool IDX, class S = ShapeAny>
 int launch_col(const ColPlan& p, hipStream_t stream) {
-  const size_t smem = ((size_t)16 * p.ldx + 2 * 16 * (NT * 16 + 4) + 2 * NT * 16 + 48) * sizeof(float);
+  const size_t smem = ((size_t)16 * p.ldx + 2 * 16 * (NT * 16 + 4) + 2 * NT * 16) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    int rc = gnc::check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_col16_kernel<NT, AGG, SAVE, IDX, S>),
+    int rc = gnc::check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_col16_kernel<NT, SAVE, IDX, S>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
                             "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc) return rc;
@@ -531,36 +482,32 @@ int launch_col(const ColPlan& p, hipStream_t stream) {
   }
   const int cap = 2 * gnc::num_cu();
   const int grid = p.num_tiles < cap ? p.num_tiles : cap;
-  mlp_col16_kernel<NT, AGG, SAVE, IDX, S><<<dim3((unsigned)grid), dim3(NT * 64), smem, stream>>>(p);
+  mlp_col16_kernel<NT, SAVE, IDX, S><<<dim3((unsigned)grid), dim3(NT * 64), smem, stream>>>(p);
   return gnc::check_launch("mlp_col16_kernel");
 }
 
 template <int NT>
-int launch_col_nt(const ColPlan& p, bool agg, bool save, bool idx, hipStream_t stream) {
-  if (idx) {
-    if (agg) return save ? launch_col<NT, true, true, true>(p, stream) : launch_col<NT, true, false, true>(p, stream);
-    return save ? launch_col<NT, false, true, true>(p, stream) : launch_col<NT, false, false, true>(p, stream);
-  }
-  if (agg) return save ? launch_col<NT, true, true, false>(p, stream) : launch_col<NT, true, false, false>(p, stream);
-  return save ? launch_col<NT, false, true, false>(p, stream) : launch_col<NT, false, false, false>(p, stream);
+int launch_col_nt(const ColPlan& p, bool save, bool idx, hipStream_t stream) {
+  if (idx) return save ? launch_col<NT, true, true>(p, stream) : launch_col<NT, false, true>(p, stream);
+  return save ? launch_col<NT, true, false>(p, stream) : launch_col<NT, false, false>(p, stream);
 }
 
 // the default model's launch shapes (ShapeProj .. ShapeDec): 0 = none of them
 enum { SHAPE_ANY = 0, SHAPE_PROJ, SHAPE_EDGE, SHAPE_NODE, SHAPE_ENC, SHAPE_DEC };
-int shape_of(const ColPlan& p, int nt, bool agg, bool save, bool idx, bool row_ids) {
+int shape_of(const ColPlan& p, int nt, bool save, bool idx, bool row_ids) {
   static const bool off = getenv("GNC_COL16_NO_SHAPES") != nullptr;  // A/B: run-time shapes only
   if (off || nt != 8 || p.H != 128 || row_ids) return SHAPE_ANY;
   const bool ln = p.gamma != nullptr, res = p.residual != nullptr;
-  if (p.L == 1 && p.k_in == 128 && p.nadd == 0 && !ln && !res && p.vec_stage && !p.narrow_w0 && !idx && !agg && !save && p.vec_out)
+  if (p.L == 1 && p.k_in == 128 && p.nadd == 0 && !ln && !res && p.vec_stage && !p.narrow_w0 && !idx && !save && p.vec_out)
     return SHAPE_PROJ;
   if (p.L != 3) return SHAPE_ANY;
   if (p.od == 128 && p.k_in == 128 && p.nadd == 2 && ln && p.res_xcol >= 0 && p.vec_stage && !p.narrow_w0 && idx && p.vec_out)
     return SHAPE_EDGE;
-  if (p.od == 128 && p.k_in == 256 && p.nadd == 0 && ln && p.res_xcol >= 0 && p.vec_stage && !p.narrow_w0 && !idx && !agg && p.vec_out)
+  if (p.od == 128 && p.k_in == 256 && p.nadd == 0 && ln && p.res_xcol >= 0 && p.vec_stage && !p.narrow_w0 && !idx && p.vec_out)
     return SHAPE_NODE;
-  if (p.od == 128 && p.k_in <= 16 && p.nseg == 1 && p.nadd == 0 && ln && !res && !p.vec_stage && p.narrow_w0 && !idx && !agg && p.vec_out)
+  if (p.od == 128 && p.k_in <= 16 && p.nseg == 1 && p.nadd == 0 && ln && !res && !p.vec_stage && p.narrow_w0 && !idx && p.vec_out)
     return SHAPE_ENC;
-  if (p.k_in == 128 && p.nadd == 0 && !ln && !res && p.vec_stage && !p.narrow_w0 && !idx && !agg) return SHAPE_DEC;
+  if (p.k_in == 128 && p.nadd == 0 && !ln && !res && p.vec_stage && !p.narrow_w0 && !idx) return SHAPE_DEC;
   return SHAPE_ANY;
 }
 
@@ -600,7 +547,6 @@ int gnc_mlp::launch_col16(const gnc_mlp_desc_t& d, hipStream_t stream, bool* lau
   p.k_in = d.in_dim[0];
   p.k0pad = (d.in_dim[0] + 15) & ~15;
   p.ldx = n0 * CK + 4;  // whole chunks: the B fragments of a chunk are read unconditionally
-  p.fix_len = gnc_mlp_agg_fix_len();
   for (int l = 0; l < L; ++l) {
     const int ldw = ldw_of(d, l);
     if ((int64_t)d.out_dim[l] * ldw * 4 > 0x7fffffffll) return GNC_OK;
@@ -673,27 +619,20 @@ int gnc_mlp::launch_col16(const gnc_mlp_desc_t& d, hipStream_t stream, bool* lau
       p.save[l] = d.save_act[l];
     }
   }
-  const bool agg = d.agg_out != nullptr;
-  if (agg && (!d.agg_index || !d.agg_fix || d.ld_agg < od || 2 * p.num_tiles > p.fix_len)) return GNC_OK;
-  p.agg_out = d.agg_out;
-  p.ld_agg = d.ld_agg;
-  p.agg_index = d.agg_index;
-  p.agg_fix = d.agg_fix;
+  if (d.agg_out) return GNC_OK;  // (never asked for: gnc_mlp_agg_supported() sends these launches to K1)
   bool idx = false;
   for (int s = 0; s < d.num_segments; ++s) idx = idx || d.seg[s].index != nullptr;
   bool row_ids = false;  // a gathered MATMUL segment (the concat form of the edge processor)
   for (int s = 0; s < p.nseg; ++s) row_ids = row_ids || p.sg[s].index != nullptr;
   *launched = true;
   if (probe_only) return GNC_OK;
-  switch (shape_of(p, nt, agg, save, idx, row_ids)) {
-    case SHAPE_PROJ: return launch_col<8, false, false, false, ShapeProj>(p, stream);
-    case SHAPE_EDGE:
-      if (agg) return save ? launch_col<8, true, true, true, ShapeEdge>(p, stream) : launch_col<8, true, false, true, ShapeEdge>(p, stream);
-      return save ? launch_col<8, false, true, true, ShapeEdge>(p, stream) : launch_col<8, false, false, true, ShapeEdge>(p, stream);
-    case SHAPE_NODE: return save ? launch_col<8, false, true, false, ShapeNode>(p, stream) : launch_col<8, false, false, false, ShapeNode>(p, stream);
-    case SHAPE_ENC: return save ? launch_col<8, false, true, false, ShapeEnc>(p, stream) : launch_col<8, false, false, false, ShapeEnc>(p, stream);
-    case SHAPE_DEC: return save ? launch_col<8, false, true, false, ShapeDec>(p, stream) : launch_col<8, false, false, false, ShapeDec>(p, stream);
+  switch (shape_of(p, nt, save, idx, row_ids)) {
+    case SHAPE_PROJ: return launch_col<8, false, false, ShapeProj>(p, stream);
+    case SHAPE_EDGE: return save ? launch_col<8, true, true, ShapeEdge>(p, stream) : launch_col<8, false, true, ShapeEdge>(p, stream);
+    case SHAPE_NODE: return save ? launch_col<8, true, false, ShapeNode>(p, stream) : launch_col<8, false, false, ShapeNode>(p, stream);
+    case SHAPE_ENC: return save ? launch_col<8, true, false, ShapeEnc>(p, stream) : launch_col<8, false, false, ShapeEnc>(p, stream);
+    case SHAPE_DEC: return save ? launch_col<8, true, false, ShapeDec>(p, stream) : launch_col<8, false, false, ShapeDec>(p, stream);
     default: break;
   }
-  return nt == 4 ? launch_col_nt<4>(p, agg, save, idx, stream) : launch_col_nt<8>(p, agg, save, idx, stream);
+  return nt == 4 ? launch_col_nt<4>(p, save, idx, stream) : launch_col_nt<8>(p, save, idx, stream);
 }

@@ -271,9 +271,19 @@ extern "C" int gnc_mlp_agg_supported(const gnc_mlp_desc_t* desc) {
   if (!probe.agg_fix) probe.agg_fix = &dummy_i;
   if (probe.ld_agg < od) probe.ld_agg = od;
   bool ok = false;
-  rc = launch_col16(probe, nullptr, &ok, true);
-  if (rc) return rc;
-  if (!ok) rc = launch_resident(probe, T, narrow_out, nullptr, &ok, true);
+  {  // small batches: the column-split kernel serves the launch WITHOUT the epilogue, and K1 on its rows afterwards
+     // (scatter_sum_csr_small) is cheaper than the epilogue's fix-up + zero-fill launches
+    gnc_mlp_desc_t plain = *desc;
+    plain.agg_out = nullptr;
+    bool small = false;
+    rc = launch_col16(plain, nullptr, &small, true);
+    if (rc) return rc;
+    if (small) {
+      gnc::set_error("gnc_mlp_agg_supported: a small batch: run gnc_scatter_sum_csr_f32 on the output rows");
+      return GNC_ERR_UNSUPPORTED;
+    }
+  }
+  rc = launch_resident(probe, T, narrow_out, nullptr, &ok, true);
   if (rc) return rc;
   if (!ok && T == 4) {  // 65..128 features: the streaming kernel carries the epilogue too
     rc = launch_stream(probe, T, narrow_out, nullptr, &ok, true);

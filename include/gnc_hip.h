@@ -208,7 +208,8 @@ typedef struct gnc_mlp_desc {
    *     those rows from `out` through the row pointers afterwards (same stream).
    * Served by the weights-resident kernel (widths <= 64), the 32-row streaming kernel (65..128) and the 16-row
    * streaming kernel (129..256, num_linear > 1): ask gnc_mlp_agg_supported(); gnc_mlp_forward_f32 returns
-   * GNC_ERR_UNSUPPORTED otherwise. */
+   * GNC_ERR_UNSUPPORTED otherwise.  Not offered for small batches at 65..128 features (gnc_mlp_small_batch_supported):
+   * there gnc_scatter_sum_csr_f32 on the output rows is the cheaper route. */
   float* agg_out;           /* [*, ld_agg] or NULL */
   int32_t ld_agg;
   const int32_t* agg_index; /* [rows] destination of each output row */

@@ -442,7 +442,9 @@ def test_fused_aggregation_epilogue_bit_equals_k1(native, n, e, hot, d):
                                 aggregate=(torch.from_numpy(dst).to(DEV), rowptr, n))
     if agg is None and (os.environ.get("GNC_MLP_NO_RESIDENT") or os.environ.get("GNC_MLP_NO_STREAM2") or os.environ.get("GNC_MLP_NO_STREAM16")):
         pytest.skip("the kernel that carries the epilogue at this width is switched off by an A/B variable")
-    assert agg is not None, "the W-split edge shape at widths 64, 128 and 256 must take the fused epilogue"
+    if agg is None:  # a small batch at 65..128 features: the column-split kernel leaves the aggregation to K1 (cheaper there)
+        assert native.small_batch_kernel_serves(segs, ws, bs, ln, "ReLU", ea, e, modes)
+        agg = native.scatter_sum_csr(y, rowptr, None, n)
     assert torch.equal(y, y0)
     ref = native.scatter_sum_csr(y, rowptr, None, n)
     assert torch.equal(agg, ref)
@@ -482,7 +484,9 @@ def test_fused_aggregation_random_shapes(native, d):
                                     modes=modes, aggregate=(dst_t, rowptr, n))
         if agg is None and (os.environ.get("GNC_MLP_NO_RESIDENT") or os.environ.get("GNC_MLP_NO_STREAM2") or os.environ.get("GNC_MLP_NO_STREAM16")):
             pytest.skip("the kernel that carries the epilogue at this width is switched off by an A/B variable")
-        assert agg is not None
+        if agg is None:  # a small batch at 65..128 features: served without the epilogue, K1 follows (see the test above)
+            assert e <= 8192 and d <= 128, (n, e, d)  # (d <= 64 only under the A/B switch GNC_COL16_D64=1)
+            continue
         assert torch.equal(agg, native.scatter_sum_csr(y, rowptr, None, n)), (n, e, k)
 
 

@@ -109,9 +109,10 @@ def test_small_batch_forward_against_float64(native, shape, rows):
 
 
 @pytest.mark.parametrize("rows,n", [(5, 3), (16, 1), (33, 40), (1984, 1024), (4000, 77)])
-def test_small_batch_aggregation_epilogue_is_k1_bit_for_bit(native, rows, n):
-    """Fused aggregation of the small-batch edge launch: destinations inside a tile come from the launch's walk, the ones a
-    tile boundary cuts from gnc_agg_fixup_f32, empty ones are zero-filled - all of them bit-identical to K1 on the rows."""
+def test_small_batch_edge_launch_leaves_aggregation_to_k1(native, rows, n):
+    """A small-batch edge launch is served WITHOUT the aggregation epilogue (the fix-up and zero-fill launches it needs cost more
+    than K1 at this size): `aggregate=` returns None for the sums, the rows are those of the plain launch, and K1 on them (the
+    one-destination-per-lane-group kernel) adds in the reference's edge order, bit for bit."""
     rng = np.random.default_rng(rows * 3 + n)
     D = 128
     dst_np = np.sort(rng.integers(0, n, size=rows))
@@ -126,11 +127,10 @@ def test_small_batch_aggregation_epilogue_is_k1_bit_for_bit(native, rows, n):
     ws, bs = zip(_lin(rng, D, D), _lin(rng, D, D), _lin(rng, D, D))
     ln = (_t(rng.uniform(0.5, 1.5, D)), _t(rng.uniform(-0.5, 0.5, D)), 1e-5)
     out, agg = native.mlp_forward(segs, list(ws), list(bs), ln=ln, residual=e, rows=rows, modes=modes, aggregate=(dst, rowptr, n))
-    assert agg is not None
+    assert agg is None
     plain = native.mlp_forward(segs, list(ws), list(bs), ln=ln, residual=e, rows=rows, modes=modes)
     assert torch.equal(out, plain)
     k1 = native.scatter_sum_csr(out, rowptr, None, n)
-    assert torch.equal(agg, k1)
     # ... and K1 itself (the one-destination-per-lane-group kernel at this size) against the reference's order of additions
     o = out.cpu().numpy()
     want = np.zeros((n, D), dtype=np.float32)
