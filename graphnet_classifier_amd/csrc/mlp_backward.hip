@@ -1218,6 +1218,14 @@ extern "C" int gnc_mlp_backward_supported(const gnc_mlp_desc_t* fwd) {
   return GNC_OK;
 }
 
+// 1 if the small-batch data kernel (mlp_bwd_col16.hip) serves this backward exactly as the operands lie: it reads neither the
+// segment tables nor (without dx) the first Linear's weight, so the caller need not make 16-B-row copies of [N, 3] inputs or
+// nn.Linear(3, H) weights.  fwd.save_act must carry the saved post-activations (see gnc_mlp_bwd_desc_t).
+extern "C" int gnc_mlp_backward_small_batch_supported(const gnc_mlp_desc_t* fwd) {
+  if (!fwd || validate_desc(fwd, false) != GNC_OK || fwd->num_linear < 2 || !fwd->save_act[0]) return 0;
+  return bwd_col16_supported(*fwd) ? 1 : 0;
+}
+
 extern "C" int gnc_mlp_backward_dx_add_honoured(const gnc_mlp_desc_t* fwd) {
   int nmm, nadd, T;
   BwdPlan pl;

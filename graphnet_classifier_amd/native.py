@@ -33,6 +33,7 @@ _SIGNATURES = {
     "gnc_mlp_save_act_supported": (c_int32, [c_void_p]),
     "gnc_mlp_agg_fix_len": (c_int32, []),
     "gnc_mlp_small_batch_supported": (c_int32, [c_void_p]),
+    "gnc_mlp_backward_small_batch_supported": (c_int32, [c_void_p]),
     "gnc_xty_small_max_rows": (c_int32, []),
     "gnc_xty_small_f32": (c_int32, [c_void_p, c_int32, c_void_p]),
     "gnc_agg_fixup_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p, c_int64,
@@ -595,11 +596,23 @@ def mlp_backward(segments, weights, biases, ln, grad_out: torch.Tensor | None, r
     ``saved_act``: the list ``mlp_forward(save_act=...)`` filled for the same call; kernels that honour it
     (gnc_mlp_backward_saved_act_honoured) read the post-activations instead of recomputing them."""
     lib = load_library()
-    segs, w, b, residual, rows, _ = _prepare_mlp(segments, weights, biases, residual, rows, modes)
-    dev = segs[0][0].device
-    dummy = torch.empty(1, w[-1].size(0), device=dev)
+    given = (segments, weights, biases, residual, rows, modes)
     bd = MlpBwdDesc()
-    bd.fwd = make_mlp_desc(segs, w, b, ln, "ReLU", 0.0, None, dummy, rows)
+    unpadded = False
+    if saved_act and len(saved_act) == len(weights) - 1:
+        # a small batch with saved activations: its data kernel reads the operands where they lie (no padded copies of the
+        # reference's 3-column inputs / first-layer weights: two pad launches each)
+        segs, w, b, residual, rows, _ = _prepare_mlp(*given, vector_rows=False)
+        dummy = torch.empty(1, w[-1].size(0), device=segs[0][0].device)
+        bd.fwd = make_mlp_desc(segs, w, b, ln, "ReLU", 0.0, None, dummy, rows)
+        for l, a in enumerate(saved_act):
+            bd.fwd.save_act[l] = a.data_ptr()
+        unpadded = lib.gnc_mlp_backward_small_batch_supported(ctypes.byref(bd.fwd)) == 1
+    if not unpadded:
+        segs, w, b, residual, rows, _ = _prepare_mlp(*given)
+        dummy = torch.empty(1, w[-1].size(0), device=segs[0][0].device)
+        bd.fwd = make_mlp_desc(segs, w, b, ln, "ReLU", 0.0, None, dummy, rows)
+    dev = segs[0][0].device
     # residual given: ask the kernel to fold its gradient (grad_out) into the dx of the segment it came from
     mm = [sg for sg in segs if sg[3] == SEG_MATMUL]
     fold = (residual is not None and need_dx and mm[-1][1] is None and mm[-1][0].data_ptr() == residual.data_ptr()

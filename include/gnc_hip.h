@@ -324,6 +324,9 @@ typedef struct gnc_mlp_bwd_desc {
 size_t gnc_sizeof_mlp_bwd_desc(void);
 int gnc_mlp_backward_supported(const gnc_mlp_desc_t* fwd /* host */);
 int gnc_mlp_backward_dx_add_honoured(const gnc_mlp_desc_t* fwd /* host */); /* 1 / 0 */
+/* ABI 18: 1 if the small-batch data kernel serves this backward with the operands exactly as they lie (fwd.save_act = the saved
+ * post-activations): no 16-B-row copies of [N, 3] inputs / nn.Linear(3, H) weights are needed in front of it */
+int gnc_mlp_backward_small_batch_supported(const gnc_mlp_desc_t* fwd /* host */);
 /* 1 if gnc_mlp_backward_f32 accepts desc->grad_gather for this description (grad_gather* and dw_partial filled in as
  * for the call), else 0: the caller then gathers the rows itself (gnc_gather_rows_f32 / gnc_gather_rows_add_f32) */
 int gnc_mlp_backward_grad_gather_honoured(const gnc_mlp_bwd_desc_t* desc /* host */);
