@@ -1389,7 +1389,7 @@ extern "C" int gnc_mlp_backward_grad_gather_honoured(const gnc_mlp_bwd_desc_t* b
   static const bool off = getenv("GNC_NO_GRAD_GATHER_FOLD") != nullptr;  // A/B switch: the caller gathers the rows itself
   if (off || !bd || !bd->grad_gather || !bd->grad_gather_index) return 0;
   if (!bd->dw_partial[0]) {  // split path: only the small-batch data kernel (saved activations) gathers in the launch
-    return (bd->act_given && gnc_mlp::validate_desc(&bd->fwd, false) == GNC_OK && (bwd_col16_supported(bd->fwd) || bwd_col16_persist_supported(bd->fwd)) &&
+    return (bd->act_given && gnc_mlp::validate_desc(&bd->fwd, false) == GNC_OK && (bwd_col16_supported(bd->fwd) || (bwd_col16_persist_supported(bd->fwd) && bd->fwd.in_dim[0] <= 128)) &&
             bd->ld_grad_gather % 4 == 0 && fused_al16(bd->grad_gather) && bd->ld_grad_gather >= bd->fwd.out_dim[bd->fwd.num_linear - 1])
                ? 1 : 0;
   }

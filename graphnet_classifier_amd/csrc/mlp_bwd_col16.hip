@@ -379,6 +379,15 @@ __global__ __launch_bounds__(512) void mlp_bwd_col16_persist_kernel(const BPlan 
   wload_tr(wt0, p.tr[0]);
   wload_tr(wt1, p.tr[1]);
   if constexpr (N0 > 0) wload_tr(wdx, p.tr[2]);
+  // a second dx chunk (in_dim[0] in 129..256: the node processor's [x | agg]) does not fit the register file: its fragments
+  // wait in LDS, in the order the lanes read them back (64 KB, wave-private slices: no barrier)
+  float* wl2 = lnbuf + 4 * NT * 16 + (size_t)w * NKB * 64 * 4;
+  if constexpr (N0 > 1) {
+    f32x4 tmp[NKB];
+    wload_tr(tmp, p.tr[3]);
+#pragma unroll
+    for (int cb = 0; cb < NKB; ++cb) *reinterpret_cast<f32x4*>(wl2 + (cb * 64 + lane) * 4) = tmp[cb];
+  }
   const f32x4 gamma4 = *reinterpret_cast<const f32x4*>(p.gamma + f0);
   const f32x4 bias4 = p.bias_last ? *reinterpret_cast<const f32x4*>(p.bias_last + f0) : f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 sum_b = {0.f, 0.f, 0.f, 0.f}, sum_g = {0.f, 0.f, 0.f, 0.f};
@@ -406,19 +415,23 @@ __global__ __launch_bounds__(512) void mlp_bwd_col16_persist_kernel(const BPlan 
   int t = blockIdx.x;
   request_rows(t);
   request_gather();
-  f32x4 dx_pending = {0.f, 0.f, 0.f, 0.f};
+  f32x4 dx_pending = {0.f, 0.f, 0.f, 0.f}, dx_pending1 = {0.f, 0.f, 0.f, 0.f};
   int dx_row = -1;  // row of dx_pending (-1: nothing pending)
-  auto store_dx = [&]() {  // (in_dim[0] <= 128 columns; rows of 16-B pieces when vec_dx)
-    if (dx_row < 0 || f0 >= p.k_in) return;
-    float* op = p.dx + (int64_t)dx_row * p.ld_dx + f0;
+  auto store_dx_chunk = [&](const f32x4& v, int c0) {  // (rows of 16-B pieces when vec_dx)
+    if (dx_row < 0 || c0 + f0 >= p.k_in) return;
+    float* op = p.dx + (int64_t)dx_row * p.ld_dx + c0 + f0;
     if (p.vec_dx) {
-      *reinterpret_cast<f32x4*>(op) = dx_pending;
+      *reinterpret_cast<f32x4*>(op) = v;
     } else {
-      op[0] = dx_pending.x;
-      if (f0 + 1 < p.k_in) op[1] = dx_pending.y;
-      if (f0 + 2 < p.k_in) op[2] = dx_pending.z;
-      if (f0 + 3 < p.k_in) op[3] = dx_pending.w;
+      op[0] = v.x;
+      if (c0 + f0 + 1 < p.k_in) op[1] = v.y;
+      if (c0 + f0 + 2 < p.k_in) op[2] = v.z;
+      if (c0 + f0 + 3 < p.k_in) op[3] = v.w;
     }
+  };
+  auto store_dx = [&]() {
+    store_dx_chunk(dx_pending, 0);
+    if constexpr (N0 > 1) store_dx_chunk(dx_pending1, CK);
   };
 
   for (; t < p.num_tiles; t += gridDim.x) {
@@ -506,6 +519,32 @@ __global__ __launch_bounds__(512) void mlp_bwd_col16_persist_kernel(const BPlan 
       dx_pending = acc0 + acc1;
       if (p.dx_add_chunk == 0) dx_pending += gv;
       dx_row = row_live ? row0 + j : -1;
+      if constexpr (N0 > 1) {  // second chunk: A fragments from the wave's LDS slice, four k blocks at a time
+        acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c0 = 0; c0 < NKB; c0 += 4) {
+          f32x4 a[4], bf[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            a[u] = *reinterpret_cast<const f32x4*>(wl2 + ((c0 + u) * 64 + lane) * 4);
+            bf[u] = *reinterpret_cast<const f32x4*>(hbuf + j * LDH + 4 * g + 16 * (c0 + u));
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u += 2) {
+            acc0 = mfma16(a[u].x, bf[u].x, acc0);
+            acc1 = mfma16(a[u + 1].x, bf[u + 1].x, acc1);
+            acc0 = mfma16(a[u].y, bf[u].y, acc0);
+            acc1 = mfma16(a[u + 1].y, bf[u + 1].y, acc1);
+            acc0 = mfma16(a[u].z, bf[u].z, acc0);
+            acc1 = mfma16(a[u + 1].z, bf[u + 1].z, acc1);
+            acc0 = mfma16(a[u].w, bf[u].w, acc0);
+            acc1 = mfma16(a[u + 1].w, bf[u + 1].w, acc1);
+          }
+        }
+        dx_pending1 = acc0 + acc1;
+        if (p.dx_add_chunk == 1) dx_pending1 += gv;
+      }
     }
     __syncthreads();  // abuf / hbuf are rewritten at the top of the next tile
   }
@@ -582,11 +621,11 @@ bool gnc_mlp::bwd_col16_persist_supported(const gnc_mlp_desc_t& d) {
     if (d.out_dim[l] != 128 || (l > 0 && d.in_dim[l] != 128) || (l == 2 && (ldw_of(d, l) % 4 != 0 || !al16b(d.weight[l]))) ||
         (int64_t)128 * ldw_of(d, l) * 4 > 0x7fffffffll)
       return false;
-  if (d.in_dim[0] > 128 || !al16b(d.ln_gamma) || (d.bias[2] && !al16b(d.bias[2]))) return false;
+  if (d.in_dim[0] > 256 || !al16b(d.ln_gamma) || (d.bias[2] && !al16b(d.bias[2]))) return false;
   const int lm = last_matmul(d);
   if (lm < 0) return false;
   // a residual's gradient is folded into dx only as the whole (one) chunk
-  if (!d.seg[lm].index && d.seg[lm].width == 128 && d.seg[lm].wcol != 0) return false;
+  if (!d.seg[lm].index && d.seg[lm].width == 128 && d.seg[lm].wcol % CK != 0) return false;
   return true;
 }
 int gnc_mlp::bwd_col16_persist_ln_partial_rows(int64_t rows) { return persist_grid(rows); }
@@ -605,7 +644,7 @@ int gnc_mlp::launch_bwd_col16_persist(const gnc_mlp_bwd_desc_t& bd, hipStream_t 
   p.rows = (int)d.rows;
   p.num_tiles = (int)gnc::ceil_div(d.rows, (int64_t)R16);
   p.L = 3; p.H = D; p.od = D;
-  p.n0 = bd.dx ? 1 : 0;
+  p.n0 = bd.dx ? (d.in_dim[0] > CK ? 2 : 1) : 0;
   p.k_in = d.in_dim[0];
   p.vec_dx = (bd.dx && bd.ld_dx % 4 == 0 && d.in_dim[0] % 4 == 0 && al16b(bd.dx)) ? 1 : 0;
   p.has_ln = 1;
@@ -623,6 +662,7 @@ int gnc_mlp::launch_bwd_col16_persist(const gnc_mlp_bwd_desc_t& bd, hipStream_t 
   p.tr[0] = {d.weight[2], ldw_of(d, 2), (127 * ldw_of(d, 2) + D) * 4, D};
   p.tr[1] = {d.weight[1], ldw_of(d, 1), (127 * ldw_of(d, 1) + D) * 4, D};
   p.tr[2] = {d.weight[0], ldw_of(d, 0), (127 * ldw_of(d, 0) + d.in_dim[0]) * 4, D};
+  if (d.in_dim[0] > CK) p.tr[3] = {d.weight[0] + CK, ldw_of(d, 0), (127 * ldw_of(d, 0) + d.in_dim[0] - CK) * 4, D};
   p.bias_last = d.bias[2];
   p.gamma = d.ln_gamma;
   p.eps = d.ln_eps;
@@ -634,15 +674,29 @@ int gnc_mlp::launch_bwd_col16_persist(const gnc_mlp_bwd_desc_t& bd, hipStream_t 
   p.gg_rows = bd.grad_gather_rows > INT32_MAX ? (uint32_t)INT32_MAX : (uint32_t)bd.grad_gather_rows;
   p.dx = bd.dx;
   p.ld_dx = bd.ld_dx;
-  p.dx_add_chunk = (bd.dx && bd.dx_add_grad_out) ? 0 : -1;
-  if (p.dx_add_chunk == 0) {
+  p.dx_add_chunk = -1;
+  if (bd.dx && bd.dx_add_grad_out) {
     const int lm = last_matmul(d);
-    GNC_REQUIRE(lm >= 0 && d.seg[lm].width == D && !d.seg[lm].index && d.seg[lm].wcol == 0 && d.in_dim[0] == D,
-                "gnc_mlp_backward_f32: dx_add_grad_out needs one row-ordered MATMUL segment as wide as the output");
+    GNC_REQUIRE(lm >= 0 && d.seg[lm].width == D && !d.seg[lm].index && d.seg[lm].wcol % CK == 0 && d.seg[lm].wcol + D <= d.in_dim[0],
+                "gnc_mlp_backward_f32: dx_add_grad_out needs a row-ordered MATMUL segment as wide as the output on a chunk boundary");
+    p.dx_add_chunk = d.seg[lm].wcol / CK;
   }
   p.ln_partial = bd.ln_partial;
-  const size_t smem = ((size_t)3 * 16 * (8 * 16 + 4) + 4 * 8 * 16) * sizeof(float);
+  const size_t smem = ((size_t)3 * 16 * (8 * 16 + 4) + 4 * 8 * 16 + (p.n0 > 1 ? (size_t)8 * NKB * 64 * 4 : 0)) * sizeof(float);
   const dim3 grid((unsigned)persist_grid(d.rows)), block(512);
+  if (p.n0 > 1) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      int rc = gnc::check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_col16_persist_kernel<2, false>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                              "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+      if (rc) return rc;
+      attr_set = true;
+    }
+    GNC_REQUIRE(!bd.grad_gather, "gnc_mlp_backward_f32: grad_gather with a two-chunk dx is not instantiated");
+    mlp_bwd_col16_persist_kernel<2, false><<<grid, block, smem, stream>>>(p);
+    return gnc::check_launch("mlp_bwd_col16_persist_kernel");
+  }
   if (bd.dx) {
     if (bd.grad_gather) mlp_bwd_col16_persist_kernel<1, true><<<grid, block, smem, stream>>>(p);
     else mlp_bwd_col16_persist_kernel<1, false><<<grid, block, smem, stream>>>(p);
