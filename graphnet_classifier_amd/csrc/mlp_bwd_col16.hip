@@ -589,7 +589,7 @@ int last_matmul(const gnc_mlp_desc_t& d) {
 // that the forward's post-activations are at hand?
 bool gnc_mlp::bwd_col16_supported(const gnc_mlp_desc_t& d) {
   static const bool off = getenv("GNC_NO_BWD_COL16") != nullptr;  // A/B switch
-  if (off || d.rows < 1 || d.rows > col16_max_rows() || d.rows >= INT32_MAX) return false;
+  if (off || d.rows < 1 || d.rows > bwd_col16_max_rows() || d.rows >= INT32_MAX) return false;
   const int L = d.num_linear;
   if (L < 2 || L > NTR) return false;
   const int H = d.out_dim[0], od = d.out_dim[L - 1];
@@ -615,7 +615,7 @@ int gnc_mlp::bwd_col16_ln_partial_rows(int64_t rows) { return (int)gnc::ceil_div
 // register-resident variant.  Shape fields and alignment only.
 bool gnc_mlp::bwd_col16_persist_supported(const gnc_mlp_desc_t& d) {
   static const bool off = getenv("GNC_NO_BWD_PERSIST") != nullptr;  // A/B switch: the 32-row streamed kernel
-  if (off || d.rows <= col16_max_rows() || d.rows >= INT32_MAX / 2) return false;
+  if (off || d.rows <= bwd_col16_max_rows() || d.rows >= INT32_MAX / 2) return false;
   if (d.num_linear != 3 || !d.ln_gamma || !d.ln_beta) return false;
   for (int l = 0; l < 3; ++l)
     if (d.out_dim[l] != 128 || (l > 0 && d.in_dim[l] != 128) || (l == 2 && (ldw_of(d, l) % 4 != 0 || !al16b(d.weight[l]))) ||

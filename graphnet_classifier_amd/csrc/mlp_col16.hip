@@ -516,11 +516,24 @@ uint32_t rows32(int64_t r) { return r > INT32_MAX ? (uint32_t)INT32_MAX : (uint3
 
 }  // namespace
 
-// Rows up to which the column-split kernel serves a description (GNC_COL16_MAX_ROWS overrides; 0 switches it off).
+// Rows up to which the column-split kernel serves a description (GNC_COL16_MAX_ROWS overrides; 0 switches it off): 128 x the
+// number of CUs (32,768: `tools/latency_sizes.py` - it beats the throughput kernels up to there, 0.60 vs 0.73 ms per replayed
+// forward of a 128 x 128 pixel graph)
 int64_t gnc_mlp::col16_max_rows() {
   static const int64_t v = [] {
     const char* e = getenv("GNC_COL16_MAX_ROWS");
-    return e ? (int64_t)atoll(e) : (int64_t)2 * R16 * gnc::num_cu();
+    return e ? (int64_t)atoll(e) : (int64_t)8 * R16 * gnc::num_cu();
+  }();
+  return v;
+}
+
+// ... and up to which the small-batch BACKWARD kernels do (data kernel, one-launch weight gradients): above it the
+// register-resident data kernel / the partial-sum products take over (GNC_BWD_COL16_MAX_ROWS overrides)
+int64_t gnc_mlp::bwd_col16_max_rows() {
+  static const int64_t v = [] {
+    const char* e = getenv("GNC_BWD_COL16_MAX_ROWS");
+    const int64_t lim = e ? (int64_t)atoll(e) : (int64_t)2 * R16 * gnc::num_cu();
+    return lim < col16_max_rows() ? lim : col16_max_rows();
   }();
   return v;
 }

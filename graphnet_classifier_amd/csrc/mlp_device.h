@@ -778,6 +778,7 @@ int launch_stream16(const gnc_mlp_desc_t& d, hipStream_t stream, bool* launched,
 // small batches (rows <= col16_max_rows()) at up to 128 features: column-split workgroups, mlp_col16.hip
 int launch_col16(const gnc_mlp_desc_t& d, hipStream_t stream, bool* launched, bool probe_only = false);
 int64_t col16_max_rows();
+int64_t bwd_col16_max_rows();
 // K8 data kernel for small batches with saved post-activations (mlp_bwd_col16.hip): shape query / partial rows / launch
 bool bwd_col16_supported(const gnc_mlp_desc_t& d);
 int bwd_col16_ln_partial_rows(int64_t rows);

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(XW * 64) void xty_small_kernel(const XJobs js) {
 
 }  // namespace
 
-extern "C" int gnc_xty_small_max_rows(void) { return (int)gnc_mlp::col16_max_rows(); }
+extern "C" int gnc_xty_small_max_rows(void) { return (int)gnc_mlp::bwd_col16_max_rows(); }
 
 extern "C" int gnc_xty_small_f32(const gnc_xty_job_t* jobs, int32_t njobs, void* stream_) {
   GNC_REQUIRE(jobs && njobs >= 1 && njobs <= GNC_XTY_MAX_JOBS, "gnc_xty_small_f32: 1..%d jobs", GNC_XTY_MAX_JOBS);

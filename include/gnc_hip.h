@@ -231,7 +231,7 @@ int gnc_mlp_forward_f32(const gnc_mlp_desc_t* desc /* host */, void* stream);
 int gnc_mlp_agg_supported(const gnc_mlp_desc_t* desc /* host */);
 int gnc_mlp_agg_fix_len(void); /* entries of agg_fix (2 per wave of the persistent grid) */
 /* ABI 18.  0 if the small-batch kernel (one 16-row tile per workgroup, the waves split the output features; rows up to
- * 32 x the number of CUs, widths 65..128, ReLU) serves this description EXACTLY AS GIVEN: it is the only kernel that reads
+ * 128 x the number of CUs, widths 65..128, ReLU) serves this description EXACTLY AS GIVEN: it is the only kernel that reads
  * tables and weights whose rows are not 16-B pieces (the reference's [N, 3] inputs and nn.Linear(3, H) weights,
  * models/GNN.py:251-253) in place; for every other launch the caller hands over zero-padded copies.  The reference's own
  * regime (one graph per call: main.py:60, utils/train_model.py:35-45, utils/inference.py:59) runs on it. */
@@ -318,6 +318,7 @@ typedef struct gnc_mlp_bwd_desc {
   /* ABI 18: with act_given, fwd.save_act[l] carries the same pointers as act[l]: the shape queries that only take the forward
    * description (gnc_mlp_backward_ln_partial_rows, gnc_mlp_backward_dx_add_honoured, gnc_mlp_backward_supported) then answer
    * for the kernel that will run - small batches (rows <= 32 x CUs, widths 65..128) with saved activations run the column-split
+   * (above that, at exactly 128 features, its register-resident variant)
    * data kernel (mlp_bwd_col16.hip): one ln_partial row per 16-row tile, grad_gather and dx_add_grad_out folded in. */
 } gnc_mlp_bwd_desc_t;
 

@@ -56,7 +56,7 @@ def _ref_forward(segs, modes, ws, bs, ln, residual):
 SHAPES = ["encoder3", "projection", "edge_wsplit", "node", "decoder", "h100", "concat_edge", "two_linears"]
 
 
-@pytest.mark.parametrize("rows", [1, 15, 16, 17, 1000, 8192])
+@pytest.mark.parametrize("rows", [1, 15, 16, 17, 1000, 8192, 20011])  # (20011: more tiles than workgroups)
 @pytest.mark.parametrize("shape", SHAPES)
 def test_small_batch_forward_against_float64(native, shape, rows):
     rng = np.random.default_rng(len(shape) * 1000 + rows)
