@@ -155,7 +155,9 @@ def test_small_graph_scatter_sum_with_permutation_bit_exact(native, n, e, d):
 
 @pytest.mark.parametrize("d,e,nadd,gather,lnorm", [(128, 1984, 2, 1, True), (128, 1000, 0, 0, True), (100, 999, 0, 0, True),
                                                    (96, 37, 2, 2, True), (128, 8192, 2, 1, True), (128, 500, 0, 0, False),
-                                                   (72, 5, 2, 0, True)])
+                                                   (72, 5, 2, 0, True),
+                                                   # above the small-batch backward limit: the register-resident data kernel
+                                                   (128, 9001, 2, 1, True), (128, 20011, 0, 0, True), (128, 12345, 2, 2, True)])
 def test_small_batch_backward_against_float64_on_saved_activations(native, d, e, nadd, gather, lnorm):
     """K8 data kernel for small batches: dz of every layer, dx (with the residual's gradient folded in), the LayerNorm
     parameter sums and the gathered output gradient (`gather`: 0 none, 1 grad_out + gathered rows, 2 gathered rows only)
