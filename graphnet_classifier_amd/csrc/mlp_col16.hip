@@ -87,6 +87,8 @@ struct ColPlan {
   float* out;
   int ld_out;
   float* save[NQ];
+  const float* w_alt;  // gridDim.y == 2 (two projections of the same rows in one launch): blockIdx.y == 1 reads this first-chunk
+  float* out_alt;      // weight and writes here
 };
 
 // Shape traits: what the launcher knows about a launch at compile time.  A launch of this kernel is a few microseconds long
@@ -283,7 +285,15 @@ __global__ __launch_bounds__(NT * 64) void mlp_col16_kernel(const ColPlan p) {
     // chunk q of the tile: q < n0: columns [q CK, ..) of the first Linear; else Linear q - n0 + 1 (widths <= 128: one chunk)
     f32x4 wr[NSET][NKB], wnar = {0.f, 0.f, 0.f, 0.f};
     if constexpr (S::NARROW != 0) wload_narrow(wnar, j, g);
-    if constexpr (S::NARROW != 1) wload(wr[0], p.ch[0], j, g);
+    if constexpr (S::NARROW != 1) {
+      if (S::L == 1 && blockIdx.y != 0) {
+        ColChunk c = p.ch[0];
+        c.w = p.w_alt;
+        wload(wr[0], c, j, g);
+      } else {
+        wload(wr[0], p.ch[0], j, g);
+      }
+    }
     else {
 #pragma unroll
       for (int cb = 0; cb < NKB; ++cb) wr[0][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -453,7 +463,7 @@ __global__ __launch_bounds__(NT * 64) void mlp_col16_kernel(const ColPlan p) {
       }
     }
     if (row_live && (S::FULLH || f0 < od)) {
-      float* op = p.out + (int64_t)(row0 + j) * p.ld_out + f0;
+      float* op = ((S::L == 1 && blockIdx.y != 0) ? p.out_alt : p.out) + (int64_t)(row0 + j) * p.ld_out + f0;
       if (S::FULLH || p.vec_out) {
         *reinterpret_cast<f32x4*>(op) = o;
       } else {
@@ -482,7 +492,7 @@ int launch_col(const ColPlan& p, hipStream_t stream) {
   }
   const int cap = 2 * gnc::num_cu();
   const int grid = p.num_tiles < cap ? p.num_tiles : cap;
-  mlp_col16_kernel<NT, SAVE, IDX, S><<<dim3((unsigned)grid), dim3(NT * 64), smem, stream>>>(p);
+  mlp_col16_kernel<NT, SAVE, IDX, S><<<dim3((unsigned)grid, p.w_alt ? 2u : 1u), dim3(NT * 64), smem, stream>>>(p);
   return gnc::check_launch("mlp_col16_kernel");
 }
 
@@ -648,4 +658,40 @@ int gnc_mlp::launch_col16(const gnc_mlp_desc_t& d, hipStream_t stream, bool* lau
     default: break;
   }
   return nt == 4 ? launch_col_nt<4>(p, save, idx, stream) : launch_col_nt<8>(p, save, idx, stream);
+}
+
+extern "C" int64_t gnc_mlp_small_batch_max_rows(void) { return gnc_mlp::col16_max_rows(); }
+
+// Two projections of the same rows in ONE launch (the W-split's node-side products x Ws^T, x Wd^T: models/GNN.py:58-61 once per
+// node): grid.y = 2 over the projection shape of the small-batch kernel.  GNC_ERR_UNSUPPORTED (nothing launched) outside that
+// shape - the caller then issues two gnc_mlp_forward_f32 launches.
+extern "C" int gnc_mlp_dual_projection_f32(const float* x, int64_t ld_x, int64_t rows, const float* wa, int64_t ld_wa, const float* wb,
+                                           int64_t ld_wb, int32_t in_dim, int32_t out_dim, float* out_a, float* out_b, int64_t ld_out,
+                                           void* stream) {
+  static const bool off = getenv("GNC_NO_DUAL_PROJECTION") != nullptr;  // A/B switch
+  if (off || !x || !wa || !wb || !out_a || !out_b || rows < 1 || rows > gnc_mlp::col16_max_rows() || in_dim != 128 || out_dim != 128 ||
+      ld_wa != ld_wb || ld_wa % 4 != 0 || ld_x % 4 != 0 || ld_out % 4 != 0 || !al16h(x) || !al16h(wa) || !al16h(wb) || !al16h(out_a) ||
+      !al16h(out_b) || (int64_t)128 * ld_wa * 4 > 0x7fffffffll) {
+    gnc::set_error("gnc_mlp_dual_projection_f32: outside the small-batch projection shape (128 -> 128, 16-B rows)");
+    return GNC_ERR_UNSUPPORTED;
+  }
+  ColPlan p = {};
+  p.rows = (int)rows;
+  p.num_tiles = (int)gnc::ceil_div(rows, (int64_t)R16);
+  p.L = 1; p.H = 128; p.od = 128;
+  p.n0 = 1; p.nq = 1;
+  p.k_in = 128; p.k0pad = 128; p.ldx = CK + 4;
+  p.out_dim[0] = 128; p.in_dim[0] = 128;
+  p.ch[0] = {wa, (int)ld_wa, (int)((127 * ld_wa + 128) * 4), 128};
+  p.w_alt = wb;
+  p.vec_stage = 1;
+  p.nseg = 1;
+  p.sg[0] = {x, nullptr, (uint32_t)INT32_MAX, 128, (int)ld_x, 0};
+  p.ps[0] = {x, nullptr, (uint32_t)INT32_MAX, (int)ld_x, 128};
+  p.res_xcol = -1;
+  p.out = out_a;
+  p.out_alt = out_b;
+  p.ld_out = (int)ld_out;
+  p.vec_out = 1;
+  return launch_col<8, false, false, ShapeProj>(p, (hipStream_t)stream);
 }

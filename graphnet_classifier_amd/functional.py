@@ -27,8 +27,7 @@ def _node_projections(x, w0, dn):
     """(x Ws^T, x Wd^T) [N, H] each: the per-node halves of the W-split first Linear (models/GNN.py:58-61).  Two launches:
     one launch over the stacked weight [Ws ; Wd] (x read once, [N, 2H] written, the halves as gather tables) measured no
     faster on the same box (c3 8.14 / 8.29 vs 8.13 / 8.25 ms per step, c2 41.51 vs 41.55) and was dropped."""
-    return (native.mlp_forward([(x, None)], [w0[:, :dn]], [None]),
-            native.mlp_forward([(x, None)], [w0[:, dn:2 * dn]], [None]))
+    return native.dual_projection(x, w0[:, :dn], w0[:, dn:2 * dn])  # (one launch for a small batch at 128 features)
 
 
 class _ScatterSumCSR(torch.autograd.Function):

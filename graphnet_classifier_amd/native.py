@@ -33,6 +33,9 @@ _SIGNATURES = {
     "gnc_mlp_save_act_supported": (c_int32, [c_void_p]),
     "gnc_mlp_agg_fix_len": (c_int32, []),
     "gnc_mlp_small_batch_supported": (c_int32, [c_void_p]),
+    "gnc_mlp_small_batch_max_rows": (c_int64, []),
+    "gnc_mlp_dual_projection_f32": (c_int32, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32,
+                                              c_void_p, c_void_p, c_int64, c_void_p]),
     "gnc_mlp_backward_small_batch_supported": (c_int32, [c_void_p]),
     "gnc_xty_small_max_rows": (c_int32, []),
     "gnc_xty_small_f32": (c_int32, [c_void_p, c_int32, c_void_p]),
@@ -550,6 +553,27 @@ def mlp_forward(segments, weights, biases, ln=None, activation: str = "ReLU", ac
             _check(lib.gnc_agg_fixup_f32(out.data_ptr(), _ld(out), rowptr.data_ptr(), fix.data_ptr(), fix.numel(), num_nodes,
                                          out.size(1), agg.data_ptr(), _ld(agg), _stream(out)), "gnc_agg_fixup_f32")
     return (out, agg) if aggregate is not None else out
+
+
+def dual_projection(x: torch.Tensor, wa: torch.Tensor, wb: torch.Tensor):
+    """(x wa^T, x wb^T) over the same rows.  One launch for the small-batch projection shape (gnc_mlp_dual_projection_f32),
+    two single-Linear launches otherwise."""
+    lib = load_library()
+    _require_cuda(x, wa, wb)
+    x, wa, wb = _rowmajor(x), _rowmajor(wa.detach()), _rowmajor(wb.detach())
+    rows = x.size(0)
+    if (1 <= rows <= lib.gnc_mlp_small_batch_max_rows() and wa.shape == wb.shape and wa.size(1) == x.size(1) == 128
+            and wa.size(0) == 128 and _ld(wa) == _ld(wb) and os.environ.get("GNC_NO_DUAL_PROJECTION") is None):
+        oa = torch.empty(rows, 128, dtype=torch.float32, device=x.device)
+        ob = torch.empty(rows, 128, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = _launch("mlp_fused_in128_h128_out128_L1x2", oa,
+                         lambda: lib.gnc_mlp_dual_projection_f32(x.data_ptr(), _ld(x), rows, wa.data_ptr(), _ld(wa), wb.data_ptr(), _ld(wb),
+                                                                 128, 128, oa.data_ptr(), ob.data_ptr(), _ld(oa), _stream(x)),
+                         2.0 * rows * 2 * 128 * 128)
+        if rc == 0:
+            return oa, ob
+    return mlp_forward([(x, None)], [wa], [None]), mlp_forward([(x, None)], [wb], [None])
 
 
 def small_batch_kernel_serves(segments, weights, biases, ln=None, activation: str = "ReLU", residual=None, rows=None,

@@ -236,6 +236,14 @@ int gnc_mlp_agg_fix_len(void); /* entries of agg_fix (2 per wave of the persiste
  * models/GNN.py:251-253) in place; for every other launch the caller hands over zero-padded copies.  The reference's own
  * regime (one graph per call: main.py:60, utils/train_model.py:35-45, utils/inference.py:59) runs on it. */
 int gnc_mlp_small_batch_supported(const gnc_mlp_desc_t* desc /* host */);
+int64_t gnc_mlp_small_batch_max_rows(void); /* the row limit of the small-batch forward kernel (128 x CUs unless overridden) */
+/* ABI 18: out_a = x wa^T and out_b = x wb^T (no bias) over the same row-ordered x [rows, in_dim] in ONE launch: the two
+ * node-side products of the W-split first Linear (models/GNN.py:58-61 formed once per node).  Only the small-batch projection
+ * shape (in_dim = out_dim = 128, rows within the small-batch limit, 16-B aligned rows, ld_wa == ld_wb): GNC_ERR_UNSUPPORTED
+ * otherwise, nothing launched - issue two gnc_mlp_forward_f32 launches then. */
+int gnc_mlp_dual_projection_f32(const float* x, int64_t ld_x, int64_t rows, const float* wa, int64_t ld_wa, const float* wb,
+                                int64_t ld_wb, int32_t in_dim, int32_t out_dim, float* out_a, float* out_b, int64_t ld_out,
+                                void* stream);
 /* 0 if gnc_mlp_forward_f32 can run this description with save_act set (every kernel but the generic fallback: ReLU, hidden
  * widths that are multiples of 4 and at most 256, aligned tables), GNC_ERR_UNSUPPORTED otherwise (shape fields only) */
 int gnc_mlp_save_act_supported(const gnc_mlp_desc_t* desc /* host */);
