@@ -97,27 +97,32 @@ struct ColPlan {
 // five shapes over and over, so those get instances in which all of it is a constant.  0 / -1 = decided at run time.
 struct ShapeAny {   // everything from the plan
   static constexpr int L = 0, N0 = 0, NADD = -1, LN = -1, RES = -1, STAGE = -1, NARROW = -1;
-  static constexpr bool FULLH = false, FULLK0 = false, ROWIDS = true;
+  static constexpr bool FULLH = false, FULLK0 = false, ROWIDS = true, TRW = false;
 };
 struct ShapeProj {  // one Linear 128 -> 128 over row-ordered rows: the W-split's node-side products
   static constexpr int L = 1, N0 = 1, NADD = 0, LN = 0, RES = 0, STAGE = 1, NARROW = 0;
-  static constexpr bool FULLH = true, FULLK0 = true, ROWIDS = false;
+  static constexpr bool FULLH = true, FULLK0 = true, ROWIDS = false, TRW = false;
+};
+struct ShapeProjT {  // one Linear over [a | b] (256) read through the TRANSPOSED weight: out = a W[:, :128] + b W[:, 128:256] (the
+  // node-side gradient of the W-split: dx = d(ps) Ws + d(pd) Wd on the nn.Linear matrix as it lies)
+  static constexpr int L = 1, N0 = 2, NADD = 0, LN = 0, RES = 0, STAGE = 1, NARROW = 0;
+  static constexpr bool FULLH = true, FULLK0 = true, ROWIDS = false, TRW = true;
 };
 struct ShapeEdge {  // edge processor, W-split: e (128) + two gathered addends, 3 Linears, LayerNorm, residual e
   static constexpr int L = 3, N0 = 1, NADD = 2, LN = 1, RES = 1, STAGE = 1, NARROW = 0;
-  static constexpr bool FULLH = true, FULLK0 = true, ROWIDS = false;
+  static constexpr bool FULLH = true, FULLK0 = true, ROWIDS = false, TRW = false;
 };
 struct ShapeNode {  // node processor: [x | agg] (256), 3 Linears, LayerNorm, residual x
   static constexpr int L = 3, N0 = 2, NADD = 0, LN = 1, RES = 1, STAGE = 1, NARROW = 0;
-  static constexpr bool FULLH = true, FULLK0 = true, ROWIDS = false;
+  static constexpr bool FULLH = true, FULLK0 = true, ROWIDS = false, TRW = false;
 };
 struct ShapeEnc {   // encoders: <= 16 raw columns (rows not made of 16-B pieces), 3 Linears, LayerNorm
   static constexpr int L = 3, N0 = 1, NADD = 0, LN = 1, RES = 0, STAGE = 0, NARROW = 1;
-  static constexpr bool FULLH = true, FULLK0 = false, ROWIDS = false;
+  static constexpr bool FULLH = true, FULLK0 = false, ROWIDS = false, TRW = false;
 };
 struct ShapeDec {   // decoder: 128 -> 128 -> 128 -> few, no LayerNorm
   static constexpr int L = 3, N0 = 1, NADD = 0, LN = 0, RES = 0, STAGE = 1, NARROW = 0;
-  static constexpr bool FULLH = false, FULLK0 = true, ROWIDS = false;
+  static constexpr bool FULLH = false, FULLK0 = true, ROWIDS = false, TRW = false;
 };
 
 // 16 readable bytes for the loads that have nothing to read (kept unconditional: see the tile loop)
@@ -176,6 +181,19 @@ __global__ __launch_bounds__(NT * 64) void mlp_col16_kernel(const ColPlan p) {
   // loaded registers: columns past the matrix are cleared by wmask at use.
   auto wload = [&](f32x4 (&wr)[NKB], const ColChunk& c, int j, int g) {
     const __amdgpu_buffer_rsrc_t win = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(c.w), 0, c.nrec, 0x00020000);
+    if constexpr (S::TRW) {  // transposed chunk: component s of block cb = W[16cb + 4g + s][16w + j] (see mlp_bwd_col16.hip)
+      const uint32_t off0 = (uint32_t)(4 * g * c.ldw + 16 * w + j) * 4u;
+      const uint32_t rowb = (uint32_t)c.ldw * 4u;
+#pragma unroll
+      for (int cb = 0; cb < NKB; ++cb) {
+        const uint32_t so = (uint32_t)(16 * cb) * rowb;
+        wr[cb].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(win, off0, so, 0));
+        wr[cb].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(win, off0, so + rowb, 0));
+        wr[cb].z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(win, off0, so + 2 * rowb, 0));
+        wr[cb].w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(win, off0, so + 3 * rowb, 0));
+      }
+      return;
+    }
     const uint32_t off0 = (uint32_t)((16 * w + j) * c.ldw + 4 * g) * 4u;
 #pragma unroll
     for (int cb = 0; cb < NKB; ++cb) wr[cb] = window_load(win, off0 + (uint32_t)(cb * 64));
@@ -694,4 +712,38 @@ extern "C" int gnc_mlp_dual_projection_f32(const float* x, int64_t ld_x, int64_t
   p.ld_out = (int)ld_out;
   p.vec_out = 1;
   return launch_col<8, false, false, ShapeProj>(p, (hipStream_t)stream);
+}
+
+// out = a W[:, 0:128] + b W[:, 128:256] for W [128, ld_w] as nn.Linear holds it (read transposed, no copy): the node-side
+// gradient of the W-split first Linear, dx = d(ps) Ws + d(pd) Wd (models/GNN.py:58-61 under autograd), in one launch for a small
+// batch.  GNC_ERR_UNSUPPORTED (nothing launched) outside that shape.
+extern "C" int gnc_mlp_projection_t2_f32(const float* a, int64_t ld_a, const float* b, int64_t ld_b, int64_t rows, const float* wmat,
+                                         int64_t ld_w, int32_t hidden, int32_t dn, float* out, int64_t ld_out, void* stream) {
+  static const bool off = getenv("GNC_NO_PROJECTION_T2") != nullptr;  // A/B switch
+  if (off || !a || !b || !wmat || !out || rows < 1 || rows > gnc_mlp::col16_max_rows() || hidden != 128 || dn != 128 || ld_a % 4 != 0 ||
+      ld_b % 4 != 0 || ld_out % 4 != 0 || ld_w < 2 * dn || !al16h(a) || !al16h(b) || !al16h(out) || (int64_t)128 * ld_w * 4 > 0x7fffffffll) {
+    gnc::set_error("gnc_mlp_projection_t2_f32: outside the small-batch shape (two [rows, 128] tables, W [128, >= 256])");
+    return GNC_ERR_UNSUPPORTED;
+  }
+  ColPlan p = {};
+  p.rows = (int)rows;
+  p.num_tiles = (int)gnc::ceil_div(rows, (int64_t)R16);
+  p.L = 1; p.H = 128; p.od = 128;
+  p.n0 = 2; p.nq = 2;
+  p.k_in = 256; p.k0pad = 256; p.ldx = 2 * CK + 4;
+  p.out_dim[0] = 128; p.in_dim[0] = 256;
+  // chunk q: contraction over the 128 rows of W, output columns [128 q, 128 q + 128): window from W + 128 q to the matrix's end
+  p.ch[0] = {wmat, (int)ld_w, (int)((127 * ld_w + 128) * 4), 128};
+  p.ch[1] = {wmat + 128, (int)ld_w, (int)((127 * ld_w + 128) * 4), 128};
+  p.vec_stage = 1;
+  p.nseg = 2;
+  p.sg[0] = {a, nullptr, (uint32_t)INT32_MAX, 128, (int)ld_a, 0};
+  p.sg[1] = {b, nullptr, (uint32_t)INT32_MAX, 128, (int)ld_b, 128};
+  p.ps[0] = {a, nullptr, (uint32_t)INT32_MAX, (int)ld_a, 128};
+  p.ps[1] = {b, nullptr, (uint32_t)INT32_MAX, (int)ld_b, 128};
+  p.res_xcol = -1;
+  p.out = out;
+  p.ld_out = (int)ld_out;
+  p.vec_out = 1;
+  return launch_col<8, false, false, ShapeProjT>(p, (hipStream_t)stream);
 }

@@ -431,8 +431,7 @@ def _edge_wsplit_backward_hip(ctx, grad_out, grad_agg=None):
     dps = native.scatter_sum_csr(dz0, csc_rowptr, csc_perm, topo.num_nodes)
     dpd = native.scatter_sum_csr(dz0, topo.rowptr, None, topo.num_nodes)
     if need[0]:  # dx = dps Ws + dpd Wd: one projection launch over [dps | dpd] with the weight [Ws ; Wd]^T
-        wt = torch.cat([ws_, wd_], dim=0).t().contiguous()  # [dn, 2h]
-        grads[0] = native.mlp_forward([(dps, None), (dpd, None)], [wt], [None])
+        grads[0] = native.projection_t2(dps, dpd, w0, dn)  # (a small batch reads W0 transposed, in one launch, without the copy)
     # every weight-gradient product of this processor (and the row sums of its LayerNorm partials) in one xty_multi call:
     # one launch for a small batch; dW_0 = [dps^T x | dpd^T x | dz0^T e] is written block by block in place
     products, slots = [], []

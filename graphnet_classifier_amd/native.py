@@ -34,6 +34,8 @@ _SIGNATURES = {
     "gnc_mlp_agg_fix_len": (c_int32, []),
     "gnc_mlp_small_batch_supported": (c_int32, [c_void_p]),
     "gnc_mlp_small_batch_max_rows": (c_int64, []),
+    "gnc_mlp_projection_t2_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int32, c_int32, c_void_p,
+                                            c_int64, c_void_p]),
     "gnc_mlp_dual_projection_f32": (c_int32, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32,
                                               c_void_p, c_void_p, c_int64, c_void_p]),
     "gnc_mlp_backward_small_batch_supported": (c_int32, [c_void_p]),
@@ -574,6 +576,26 @@ def dual_projection(x: torch.Tensor, wa: torch.Tensor, wb: torch.Tensor):
         if rc == 0:
             return oa, ob
     return mlp_forward([(x, None)], [wa], [None]), mlp_forward([(x, None)], [wb], [None])
+
+
+def projection_t2(a: torch.Tensor, b: torch.Tensor, w: torch.Tensor, dn: int):
+    """a W[:, :dn] + b W[:, dn:2 dn] with W [H, >= 2 dn] as nn.Linear holds it.  One launch on the transposed-read small-batch
+    shape (gnc_mlp_projection_t2_f32); otherwise a projection launch over [a | b] with the transposed, stacked weight."""
+    lib = load_library()
+    _require_cuda(a, b, w)
+    a, b, w = _rowmajor(a), _rowmajor(b), _rowmajor(w.detach())
+    rows, h = a.size(0), w.size(0)
+    if (1 <= rows <= lib.gnc_mlp_small_batch_max_rows() and h == dn == 128 and a.shape == b.shape == (rows, h) and w.size(1) >= 2 * dn
+            and os.environ.get("GNC_NO_PROJECTION_T2") is None):
+        out = torch.empty(rows, dn, dtype=torch.float32, device=a.device)
+        with torch.cuda.device(a.device):
+            rc = _launch("mlp_fused_in256_h128_out128_L1t", out,
+                         lambda: lib.gnc_mlp_projection_t2_f32(a.data_ptr(), _ld(a), b.data_ptr(), _ld(b), rows, w.data_ptr(), _ld(w), h, dn,
+                                                               out.data_ptr(), _ld(out), _stream(a)), 2.0 * rows * 2 * h * dn)
+        if rc == 0:
+            return out
+    wt = torch.cat([w[:, :dn], w[:, dn:2 * dn]], dim=0).t().contiguous()  # [dn, 2h]
+    return mlp_forward([(a, None), (b, None)], [wt], [None])
 
 
 def small_batch_kernel_serves(segments, weights, biases, ln=None, activation: str = "ReLU", residual=None, rows=None,

@@ -236,6 +236,11 @@ int gnc_mlp_agg_fix_len(void); /* entries of agg_fix (2 per wave of the persiste
  * models/GNN.py:251-253) in place; for every other launch the caller hands over zero-padded copies.  The reference's own
  * regime (one graph per call: main.py:60, utils/train_model.py:35-45, utils/inference.py:59) runs on it. */
 int gnc_mlp_small_batch_supported(const gnc_mlp_desc_t* desc /* host */);
+/* ABI 18: out = a W[:, 0:dn] + b W[:, dn:2 dn] for W [hidden, ld_w] as nn.Linear holds it (read transposed, no copy): the
+ * node-side gradient of the W-split first Linear (dx = d(ps) Ws + d(pd) Wd) in one launch for a small batch (hidden = dn = 128,
+ * 16-B aligned rows); GNC_ERR_UNSUPPORTED otherwise, nothing launched. */
+int gnc_mlp_projection_t2_f32(const float* a, int64_t ld_a, const float* b, int64_t ld_b, int64_t rows, const float* w, int64_t ld_w,
+                              int32_t hidden, int32_t dn, float* out, int64_t ld_out, void* stream);
 int64_t gnc_mlp_small_batch_max_rows(void); /* the row limit of the small-batch forward kernel (128 x CUs unless overridden) */
 /* ABI 18: out_a = x wa^T and out_b = x wb^T (no bias) over the same row-ordered x [rows, in_dim] in ONE launch: the two
  * node-side products of the W-split first Linear (models/GNN.py:58-61 formed once per node).  Only the small-batch projection

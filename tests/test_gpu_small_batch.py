@@ -229,3 +229,19 @@ def test_xty_multi_products_and_row_sums(native):
     # more jobs than one launch carries
     many, _ = native.xty_multi([(a3, b3, None)] * 11)
     assert all(torch.equal(c, res[2][0]) for c, _ in many)
+
+
+@pytest.mark.parametrize("rows", [1, 1000, 20011, 40000])
+def test_projection_launches_of_the_wsplit(native, rows):
+    """The W-split's node-side products in one launch each: (x Ws^T, x Wd^T) forward, d(ps) Ws + d(pd) Wd backward (W0 read
+    transposed where it lies); 40000 rows: above the small-batch limit, the two-launch / copied-weight routes."""
+    rng = np.random.default_rng(rows)
+    D = 128
+    w0 = _t(rng.uniform(-0.1, 0.1, (D, 3 * D)))
+    x, a, b = (_t(rng.standard_normal((rows, D))) for _ in range(3))
+    ps, pd = native.dual_projection(x, w0[:, :D], w0[:, D:2 * D])
+    for got, want in ((ps, _D(x) @ _D(w0[:, :D]).t()), (pd, _D(x) @ _D(w0[:, D:2 * D]).t())):
+        assert float((_D(got) - want).abs().max()) < TOL * max(1.0, float(want.abs().max()))
+    dx = native.projection_t2(a, b, w0, D)
+    want = _D(a) @ _D(w0[:, :D]) + _D(b) @ _D(w0[:, D:2 * D])
+    assert float((_D(dx) - want).abs().max()) < TOL * max(1.0, float(want.abs().max()))
