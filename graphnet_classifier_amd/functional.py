@@ -152,7 +152,8 @@ def _fused_mlp_backward_hip(meta: _MlpMeta, args, need, grad_out, saved_act=None
     residual = rest[-1] if meta.has_residual else None
     segments = list(zip(tables, meta.indices))
     if (meta.activation != "ReLU" or l < 2 or not grad_out.is_cuda
-            or not native.mlp_backward_supported(segments, weights, biases, ln, meta.activation, residual, meta.rows)):
+            or not native.mlp_backward_supported(segments, weights, biases, ln, meta.activation, residual, meta.rows,
+                                                 saved_act=saved_act)):
         return None
     grad_out = grad_out.contiguous()
     need_tables = any(need[:s])

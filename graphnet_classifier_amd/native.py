@@ -610,11 +610,20 @@ def small_batch_kernel_serves(segments, weights, biases, ln=None, activation: st
 
 
 # --------------------------------------------------------------------------- K8 backward
-def mlp_backward_supported(segments, weights, biases, ln, activation, residual, rows, modes=None) -> bool:
-    """Shape query of the HIP backward kernel (ReLU, widths <= 64, 2..7 Linear layers ...)."""
+def mlp_backward_supported(segments, weights, biases, ln, activation, residual, rows, modes=None, saved_act=None) -> bool:
+    """Shape query of the HIP backward kernel (ReLU, widths <= 64, 2..7 Linear layers ...).  With ``saved_act`` a small batch
+    is asked about as its operands lie (its data kernel needs no padded copies, so the query makes none either)."""
     lib = load_library()
     if activation not in ACTIVATIONS or not (1 <= len(weights) <= GNC_MAX_LINEAR) or len(segments) > GNC_MAX_SEGMENTS:
         return False
+    if saved_act and activation == "ReLU" and len(saved_act) == len(weights) - 1:
+        segs, w, b, res, rows_, _ = _prepare_mlp(segments, weights, biases, residual, rows, modes, vector_rows=False)
+        dummy = torch.empty(1, w[-1].size(0), device=segs[0][0].device)
+        desc = make_mlp_desc(segs, w, b, ln, activation, 0.0, res, dummy, rows_)
+        for l, a in enumerate(saved_act):
+            desc.save_act[l] = a.data_ptr()
+        if lib.gnc_mlp_backward_small_batch_supported(ctypes.byref(desc)) == 1:
+            return True
     segs, w, b, res, rows, _ = _prepare_mlp(segments, weights, biases, residual, rows, modes)
     dummy = torch.empty(1, w[-1].size(0), device=segs[0][0].device)
     desc = make_mlp_desc(segs, w, b, ln, activation, 0.0, res, dummy, rows)
