@@ -158,7 +158,14 @@ __global__ __launch_bounds__(NT * 64) void mlp_bwd_col16_kernel(const BPlan p) {
     f32x4 wr[NSET][NKB];
     wload_fw(wr[0], p.fw, j, g);
     const f32x4 gamma4 = param4(p.gamma, od, f0), bias4 = param4(p.bias_last, od, f0);
-    f32x4 gv = *reinterpret_cast<const f32x4*>((p.has_g && f0 < od) ? p.grad_out + (int64_t)myrow * p.ld_g + f0 : gnc_bcol_dummy);
+    // (grad_out through a bounds-checked window: rows narrower than 16 B - the decoder's [rows, 1] - are read where they lie,
+    // the components past the output width are cleared below, a read past the last row returns zeros)
+    f32x4 gv;
+    {
+      const __amdgpu_buffer_rsrc_t gw = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(p.grad_out), 0, p.has_g ? (int)(((int64_t)(rows - 1) * p.ld_g + od) * 4) : 0, 0x00020000);
+      gv = window_load(gw, (uint32_t)((int64_t)myrow * p.ld_g + f0) * 4u);
+    }
     f32x4 sa = *reinterpret_cast<const f32x4*>((p.has_ln && sc4 * 4 < H) ? p.act[L - 2] + (int64_t)srow * H + sc4 * 4 : gnc_bcol_dummy);
     f32x4 am[NTR - 1];  // a_l rows in the accumulator layout: the ReLU masks
 #pragma unroll
@@ -711,8 +718,8 @@ int gnc_mlp::launch_bwd_col16(const gnc_mlp_bwd_desc_t& bd, hipStream_t stream) 
   const gnc_mlp_desc_t& d = bd.fwd;
   const int L = d.num_linear, H = d.out_dim[0], od = d.out_dim[L - 1];
   GNC_REQUIRE(bd.grad_out || bd.grad_gather, "gnc_mlp_backward_f32: grad_out is null");
-  GNC_REQUIRE(!bd.grad_out || (bd.ld_grad_out % 4 == 0 && al16b(bd.grad_out) && bd.ld_grad_out >= od),
-              "gnc_mlp_backward_f32: grad_out must be 16-B aligned with ld %% 4 == 0");
+  GNC_REQUIRE(!bd.grad_out || (bd.ld_grad_out >= od && (int64_t)d.rows * bd.ld_grad_out * 4 <= 0x7fffffffll),
+              "gnc_mlp_backward_f32: grad_out: ld < out_dim (or a table beyond 2 GiB)");
   GNC_REQUIRE(!bd.grad_gather || (bd.ld_grad_gather % 4 == 0 && al16b(bd.grad_gather) && bd.grad_gather_index && bd.ld_grad_gather >= od),
               "gnc_mlp_backward_f32: grad_gather must be 16-B aligned with ld %% 4 == 0");
   GNC_REQUIRE(!d.ln_gamma || bd.ln_partial, "gnc_mlp_backward_f32: the small-batch kernel forms the LayerNorm sums itself (ln_partial)");

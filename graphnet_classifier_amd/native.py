@@ -712,7 +712,8 @@ def mlp_backward(segments, weights, biases, ln, grad_out: torch.Tensor | None, r
             bd.grad_gather = bd.grad_gather_index = None
             bd.ld_grad_gather = bd.grad_gather_rows = 0
             gt = gi = None
-    g = _vector_rows(_rowmajor(grad_out)) if grad_out is not None else None
+    # (the small-batch data kernel reads grad_out rows of any width where they lie: no padded copy of the decoder's [rows, 1])
+    g = (_rowmajor(grad_out) if unpadded else _vector_rows(_rowmajor(grad_out))) if grad_out is not None else None
     if g is not None:
         bd.grad_out, bd.ld_grad_out = g.data_ptr(), _ld(g)
     g_sum = None
