@@ -104,7 +104,12 @@ __global__ __launch_bounds__(XW * 64) void xty_small_kernel(const XJobs js) {
 
 }  // namespace
 
-extern "C" int gnc_xty_small_max_rows(void) { return (int)gnc_mlp::bwd_col16_max_rows(); }
+extern "C" int gnc_xty_small_max_rows(void) {
+  // 96 x CUs (24,576): measured against the partial-sum products per captured training step of R x R pixel graphs
+  // (tools/latency_sizes.py): 1.67 -> 1.53 ms at 16 k edge rows, 1.96 -> 1.75 at 18 k, but 2.45 -> 2.61 at 32 k
+  static const int v = getenv("GNC_XTY_SMALL_MAX_ROWS") ? atoi(getenv("GNC_XTY_SMALL_MAX_ROWS")) : 6 * R16 * gnc::num_cu();
+  return v;
+}
 
 extern "C" int gnc_xty_small_f32(const gnc_xty_job_t* jobs, int32_t njobs, void* stream_) {
   GNC_REQUIRE(jobs && njobs >= 1 && njobs <= GNC_XTY_MAX_JOBS, "gnc_xty_small_f32: 1..%d jobs", GNC_XTY_MAX_JOBS);
