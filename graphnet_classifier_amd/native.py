@@ -450,6 +450,24 @@ def _vector_rows(t: torch.Tensor) -> torch.Tensor:
     return torch.nn.functional.pad(t, (0, cols - t.size(1)))[:, :t.size(1)]
 
 
+_SMALL_ROWS = None
+
+
+def _small_batch_rows(lib) -> int:
+    """Row limit of the small-batch forward kernel (asked once)."""
+    global _SMALL_ROWS
+    if _SMALL_ROWS is None:
+        _SMALL_ROWS = int(lib.gnc_mlp_small_batch_max_rows())
+    return _SMALL_ROWS
+
+
+def _rows_of(segments, rows) -> int:
+    if rows is not None:
+        return int(rows)
+    t0, i0 = segments[0]
+    return int(i0.numel() if i0 is not None else t0.size(0))
+
+
 def _prepare_mlp(segments, weights, biases, residual, rows, modes, vector_rows: bool = True):
     """Shared argument preparation of the forward and backward launches (see mlp_forward).  ``vector_rows=False`` hands
     tables and weights over as they are (row-major, any alignment): only for a launch the small-batch kernel takes."""
@@ -519,11 +537,12 @@ def mlp_forward(segments, weights, biases, ln=None, activation: str = "ReLU", ac
     ``save_need_dx`` says whether that backward will want the input gradient (``need_dx``)."""
     lib = load_library()
     given = (segments, weights, biases, residual, rows, modes)
-    segs, weights, biases, residual, rows, modes = _prepare_mlp(*given, vector_rows=False)
+    small = _rows_of(segments, rows) <= _small_batch_rows(lib)
+    segs, weights, biases, residual, rows, modes = _prepare_mlp(*given, vector_rows=not small)
     dev = segs[0][0].device
     out = torch.empty(rows, weights[-1].size(0), dtype=torch.float32, device=dev)
     desc = make_mlp_desc(segs, weights, biases, ln, activation, act_param, residual, out, rows)
-    if lib.gnc_mlp_small_batch_supported(ctypes.byref(desc)) != 0:
+    if small and lib.gnc_mlp_small_batch_supported(ctypes.byref(desc)) != 0:
         # every other kernel reads rows as 16-B pieces: 3-column inputs / [H, 3] weights go through a zero-padded copy
         # (one pad launch each); the small-batch kernel reads them where they lie
         segs, weights, biases, residual, rows, modes = _prepare_mlp(*given)
@@ -616,7 +635,7 @@ def mlp_backward_supported(segments, weights, biases, ln, activation, residual, 
     lib = load_library()
     if activation not in ACTIVATIONS or not (1 <= len(weights) <= GNC_MAX_LINEAR) or len(segments) > GNC_MAX_SEGMENTS:
         return False
-    if saved_act and activation == "ReLU" and len(saved_act) == len(weights) - 1:
+    if saved_act and activation == "ReLU" and len(saved_act) == len(weights) - 1 and _rows_of(segments, rows) <= _small_batch_rows(lib):
         segs, w, b, res, rows_, _ = _prepare_mlp(segments, weights, biases, residual, rows, modes, vector_rows=False)
         dummy = torch.empty(1, w[-1].size(0), device=segs[0][0].device)
         desc = make_mlp_desc(segs, w, b, ln, activation, 0.0, res, dummy, rows_)
@@ -654,7 +673,7 @@ def mlp_backward(segments, weights, biases, ln, grad_out: torch.Tensor | None, r
     given = (segments, weights, biases, residual, rows, modes)
     bd = MlpBwdDesc()
     unpadded = False
-    if saved_act and len(saved_act) == len(weights) - 1:
+    if saved_act and len(saved_act) == len(weights) - 1 and _rows_of(segments, rows) <= _small_batch_rows(lib):
         # a small batch with saved activations: its data kernel reads the operands where they lie (no padded copies of the
         # reference's 3-column inputs / first-layer weights: two pad launches each)
         segs, w, b, residual, rows, _ = _prepare_mlp(*given, vector_rows=False)
