@@ -494,6 +494,10 @@ __global__ __launch_bounds__(NT * 64) void mlp_col16_kernel(const ColPlan p) {
 
     CPROBE(7);  // rows stored
     CPROBE(8);
+    // More tiles than workgroups: the next tile's staging must not overwrite the input tile under a wave that is still reading
+    // it - the residual is read from it after the last barrier of the tile, and a lone Linear has no barrier behind its MFMAs
+    // at all.  (Never taken in the one-tile-per-workgroup regime.)
+    if (t + (int)gridDim.x < p.num_tiles) __syncthreads();
   }
 }
 
