@@ -245,3 +245,39 @@ def test_projection_launches_of_the_wsplit(native, rows):
     dx = native.projection_t2(a, b, w0, D)
     want = _D(a) @ _D(w0[:, :D]) + _D(b) @ _D(w0[:, D:2 * D])
     assert float((_D(dx) - want).abs().max()) < TOL * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("rows", [8192 + 16, 30000])
+def test_mid_size_launches_are_bitwise_reproducible(native, rows):
+    """More tiles than workgroups (the tile loop of the small-batch kernels, the register-resident data kernel): ten launches
+    of the edge / node / projection shapes and of their backward give the same bits - a missing barrier between tiles shows up
+    here as run-to-run noise."""
+    rng = np.random.default_rng(rows)
+    n, D = 2001, 128
+    src = torch.from_numpy(rng.integers(0, n, size=rows).astype(np.int32)).to(DEV)
+    dst = torch.from_numpy(np.sort(rng.integers(0, n, size=rows)).astype(np.int32)).to(DEV)
+    ln = (_t(rng.uniform(0.5, 1.5, D)), _t(rng.uniform(-0.5, 0.5, D)), 1e-5)
+    e = _t(rng.standard_normal((rows, D)))
+    x2 = _t(rng.standard_normal((rows, D)))
+    edge = ([(_t(rng.standard_normal((n, D))), src), (_t(rng.standard_normal((n, D))), dst), (e, None)],
+            [native.SEG_ADD, native.SEG_ADD, native.SEG_MATMUL], [_lin(rng, D, D) for _ in range(3)], e)
+    node = ([(e, None), (x2, None)], None, [_lin(rng, D, 2 * D), _lin(rng, D, D), _lin(rng, D, D)], e)
+    gout = _t(rng.standard_normal((rows, D)))
+    for segs, modes, wb, res in (edge, node):
+        ws, bs = [w for w, _ in wb], [b for _, b in wb]
+        acts = []
+        first = native.mlp_forward(segs, ws, bs, ln=ln, residual=res, rows=rows, modes=modes, save_act=acts)
+        r0 = native.mlp_backward(segs, ws, bs, ln, gout, rows=rows, modes=modes, need_dx=True, residual=res, saved_act=acts)
+        for _ in range(9):
+            again = native.mlp_forward(segs, ws, bs, ln=ln, residual=res, rows=rows, modes=modes)
+            assert torch.equal(first, again)
+            r = native.mlp_backward(segs, ws, bs, ln, gout, rows=rows, modes=modes, need_dx=True, residual=res, saved_act=acts)
+            assert torch.equal(r["dx"], r0["dx"]) and all(torch.equal(a, b) for a, b in zip(r["dz"], r0["dz"]))
+            assert all(torch.equal(a, b) for a, b in zip(r["ln_sums"], r0["ln_sums"]))
+    w0 = _t(rng.uniform(-0.1, 0.1, (D, 3 * D)))
+    p0 = native.dual_projection(e, w0[:, :D], w0[:, D:2 * D])
+    t0 = native.projection_t2(e, x2, w0, D)
+    for _ in range(9):
+        p = native.dual_projection(e, w0[:, :D], w0[:, D:2 * D])
+        assert torch.equal(p[0], p0[0]) and torch.equal(p[1], p0[1])
+        assert torch.equal(native.projection_t2(e, x2, w0, D), t0)
