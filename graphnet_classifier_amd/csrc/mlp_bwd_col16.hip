@@ -553,7 +553,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_col16_persist_kernel(const BPlan 
         if (p.dx_add_chunk == 1) dx_pending1 += gv;
       }
     }
-    __syncthreads();  // abuf / hbuf are rewritten at the top of the next tile
+    // (no barrier here: every buffer the next tile rewrites was last read in front of a barrier all waves have passed by then)
   }
   if constexpr (N0 > 0) store_dx();
   // ---- d beta / d gamma: this workgroup's partial row
