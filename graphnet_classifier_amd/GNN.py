@@ -26,6 +26,8 @@ from .topology import GraphTopology, get_destination_csr, get_topology
 # Algebraic split of the edge processor's first Linear (DESIGN.md, K4 "W-split"); GNC_NO_WSPLIT=1
 # keeps the reference-form concat for A/B measurements.
 WSPLIT = os.environ.get("GNC_NO_WSPLIT") is None
+# A/B switch: GNC_NO_READOUT_KERNEL=1 leaves the single-graph read-out classifier to PyTorch-ROCm (3 GEMM + 2 clamp + copies)
+READOUT_HIP = os.environ.get("GNC_NO_READOUT_KERNEL") is None
 # Inference: the edge processor's launch also forms the node model's per-destination sums (fused aggregation
 # epilogue); GNC_NO_FUSED_AGG=1 keeps K1 as a separate launch for A/B measurements.
 FUSED_AGG = os.environ.get("GNC_NO_FUSED_AGG") is None
@@ -332,6 +334,11 @@ class LinearClassifier(nn.Module):
         self.relu = nn.ReLU()
 
     def forward(self, x):
+        if (READOUT_HIP and x.dim() == 1 and x.is_cuda and x.dtype == torch.float32 and self.fc1.weight.is_cuda
+                and self.fc1.out_features <= native.READOUT_MAX_HIDDEN and self.fc2.out_features <= native.READOUT_MAX_HIDDEN
+                and self.fc3.out_features <= native.READOUT_MAX_CLASSES):
+            # ONE graph (the reference's loops): the three matrix-vector products in one launch each way (csrc/readout.hip)
+            return Fn.readout(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, self.fc3.weight, self.fc3.bias)
         x = self.relu(self.fc1(x))
         x = self.relu(self.fc2(x))
         return self.fc3(x)

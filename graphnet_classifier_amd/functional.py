@@ -496,6 +496,32 @@ def edge_processor_wsplit_aggregated(x, e, topo, weights, biases, ln, activation
                               aggregate=(topo.dst_sorted, topo.rowptr, topo.num_nodes))
 
 
+class _Readout(torch.autograd.Function):
+    """LinearClassifier.forward for ONE graph (models/GNN.py:312-325) as one launch each way (csrc/readout.hip)."""
+
+    @staticmethod
+    def forward(ctx, y, w1, b1, w2, b2, w3, b3):
+        logits, h1, h2 = native.readout_forward(y, w1, b1, w2, b2, w3, b3)
+        ctx.save_for_backward(y, w1, w2, w3, h1, h2)
+        ctx.has_bias = (b1 is not None, b2 is not None, b3 is not None)
+        return logits
+
+    @staticmethod
+    def backward(ctx, grad_logits):
+        y, w1, w2, w3, h1, h2 = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        dy, dw1, db1, dw2, db2, dw3, db3 = native.readout_backward(grad_logits, y, w1, w2, w3, h1, h2, need_dy=need[0])
+        hb = ctx.has_bias
+        return (dy.view_as(y) if need[0] else None, dw1 if need[1] else None, db1 if (need[2] and hb[0]) else None,
+                dw2 if need[3] else None, db2 if (need[4] and hb[1]) else None, dw3 if need[5] else None,
+                db3 if (need[6] and hb[2]) else None)
+
+
+def readout(y, w1, b1, w2, b2, w3, b3):
+    """Single-graph read-out MLP; ``y`` 1-D float32 on the GPU."""
+    return _Readout.apply(y, w1, b1, w2, b2, w3, b3)
+
+
 def edge_features(pos: torch.Tensor, src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
     """[pos[dst]-pos[src], L1 norm] per edge (models/GNN.py:299-302).  ``pos`` is input data
     (utils/dataloader.py:50); gradients with respect to it are not provided."""

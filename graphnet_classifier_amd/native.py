@@ -39,6 +39,11 @@ _SIGNATURES = {
     "gnc_mlp_dual_projection_f32": (c_int32, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32,
                                               c_void_p, c_void_p, c_int64, c_void_p]),
     "gnc_mlp_backward_small_batch_supported": (c_int32, [c_void_p]),
+    "gnc_readout_forward_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_int64, c_void_p, c_int32,
+                                          c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gnc_readout_backward_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int32, c_void_p,
+                                           c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_void_p]),
     "gnc_xty_small_max_rows": (c_int32, []),
     "gnc_xty_small_f32": (c_int32, [c_void_p, c_int32, c_void_p]),
     "gnc_agg_fixup_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p, c_int64,
@@ -574,6 +579,60 @@ def mlp_forward(segments, weights, biases, ln=None, activation: str = "ReLU", ac
             _check(lib.gnc_agg_fixup_f32(out.data_ptr(), _ld(out), rowptr.data_ptr(), fix.data_ptr(), fix.numel(), num_nodes,
                                          out.size(1), agg.data_ptr(), _ld(agg), _stream(out)), "gnc_agg_fixup_f32")
     return (out, agg) if aggregate is not None else out
+
+
+READOUT_MAX_HIDDEN, READOUT_MAX_CLASSES = 1024, 64
+_readout_tickets: dict = {}
+
+
+def _readout_ticket(dev) -> torch.Tensor:
+    """One zeroed device counter per device (every launch leaves it at 0)."""
+    key = str(dev)
+    if key not in _readout_tickets:
+        _readout_tickets[key] = torch.zeros(1, dtype=torch.int32, device=dev)
+    return _readout_tickets[key]
+
+
+def readout_forward(y, w1, b1, w2, b2, w3, b3):
+    """logits [C] = fc3(relu(fc2(relu(fc1(y))))) for ONE flattened graph output y [F] in one launch (gnc_readout_forward_f32);
+    also returns the two post-ReLU hidden vectors for the backward."""
+    lib = load_library()
+    _require_cuda(y, w1, w2, w3)
+    y = y.contiguous()
+    w1, w2, w3 = _rowmajor(w1.detach()), _rowmajor(w2.detach()), _rowmajor(w3.detach())
+    dev = y.device
+    h1 = torch.empty(w1.size(0), dtype=torch.float32, device=dev)
+    h2 = torch.empty(w2.size(0), dtype=torch.float32, device=dev)
+    logits = torch.empty(w3.size(0), dtype=torch.float32, device=dev)
+    bp = [b.detach().contiguous() if b is not None else None for b in (b1, b2, b3)]
+    with torch.cuda.device(dev):
+        _check(_launch("readout_forward", y,
+                       lambda: lib.gnc_readout_forward_f32(y.data_ptr(), y.numel(), w1.data_ptr(), _ld(w1), bp[0].data_ptr() if bp[0] is not None else None,
+                                                           w1.size(0), w2.data_ptr(), _ld(w2), bp[1].data_ptr() if bp[1] is not None else None, w2.size(0),
+                                                           w3.data_ptr(), _ld(w3), bp[2].data_ptr() if bp[2] is not None else None, w3.size(0),
+                                                           h1.data_ptr(), h2.data_ptr(), logits.data_ptr(), _readout_ticket(dev).data_ptr(), _stream(y)),
+                       2.0 * (w1.numel() + w2.numel() + w3.numel())), "gnc_readout_forward_f32")
+    return logits, h1, h2
+
+
+def readout_backward(grad_logits, y, w1, w2, w3, h1, h2, need_dy: bool = True):
+    """All gradients of ``readout_forward`` in one launch: (dy or None, dW1, db1, dW2, db2, dW3, db3)."""
+    lib = load_library()
+    g = grad_logits.contiguous()
+    y = y.contiguous()
+    w1, w2, w3 = _rowmajor(w1.detach()), _rowmajor(w2.detach()), _rowmajor(w3.detach())
+    dev = y.device
+    e = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)  # noqa: E731
+    dw1, db1, dw2, db2, dw3, db3 = e(*w1.shape), e(w1.size(0)), e(*w2.shape), e(w2.size(0)), e(*w3.shape), e(w3.size(0))
+    dy = e(y.numel()) if need_dy else None
+    with torch.cuda.device(dev):
+        _check(_launch("readout_backward", y,
+                       lambda: lib.gnc_readout_backward_f32(g.data_ptr(), y.data_ptr(), y.numel(), w1.data_ptr(), _ld(w1), w1.size(0), w2.data_ptr(),
+                                                            _ld(w2), w2.size(0), w3.data_ptr(), _ld(w3), w3.size(0), h1.data_ptr(), h2.data_ptr(),
+                                                            dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(), dw3.data_ptr(),
+                                                            db3.data_ptr(), dy.data_ptr() if dy is not None else None, _stream(y)),
+                       4.0 * w1.numel()), "gnc_readout_backward_f32")
+    return dy, dw1, db1, dw2, db2, dw3, db3
 
 
 def dual_projection(x: torch.Tensor, wa: torch.Tensor, wb: torch.Tensor):

@@ -407,6 +407,19 @@ int gnc_layer_norm_backward_f32(const float* y, int64_t ld_y, const float* gamma
                                 int64_t rows, int32_t width, float eps, float* grad_y, int64_t ld_gy, float* yhat,
                                 int64_t ld_yhat, void* stream);
 
+/* ---- read-out classifier of ONE graph (ABI 18) -------------------------------------------------------------------
+ * Replaces `LinearClassifier.forward` (models/GNN.py:312-325, called at :340) for the single-graph call of the reference's loops:
+ * logits = fc3(relu(fc2(relu(fc1(y))))) over the flattened node outputs y [F]; weights as nn.Linear holds them.  One launch
+ * forward (h1 [H1], h2 [H2]: the post-ReLU hidden vectors, kept for the backward; `ticket`: a device uint32 that is 0 before the
+ * first launch and is left at 0 by every launch), one launch backward (all six parameter gradients, contiguous, and dy [F];
+ * dy may be NULL).  H1, H2 <= 1024, C <= 64.  Fixed summation order (bitwise reproducible). */
+int gnc_readout_forward_f32(const float* y, int64_t F, const float* w1, int64_t ld1, const float* b1, int32_t H1, const float* w2,
+                            int64_t ld2, const float* b2, int32_t H2, const float* w3, int64_t ld3, const float* b3, int32_t C, float* h1,
+                            float* h2, float* logits, uint32_t* ticket, void* stream);
+int gnc_readout_backward_f32(const float* grad_logits, const float* y, int64_t F, const float* w1, int64_t ld1, int32_t H1, const float* w2,
+                             int64_t ld2, int32_t H2, const float* w3, int64_t ld3, int32_t C, const float* h1, const float* h2, float* dw1,
+                             float* db1, float* dw2, float* db2, float* dw3, float* db3, float* dy, void* stream);
+
 /* ---- graph construction on the device ---------------------------
  * Inputs: an already resized uint8 RGB image [H, W, C] in HBM.  Outputs: the tensors
  * utils/dataloader.py:49-51 builds (x, pos float32; edge_index int64 [2, E] row-major), in the

@@ -281,3 +281,26 @@ def test_mid_size_launches_are_bitwise_reproducible(native, rows):
         p = native.dual_projection(e, w0[:, :D], w0[:, D:2 * D])
         assert torch.equal(p[0], p0[0]) and torch.equal(p[1], p0[1])
         assert torch.equal(native.projection_t2(e, x2, w0, D), t0)
+
+
+@pytest.mark.parametrize("F,h1,h2,c", [(1024, 128, 32, 2), (16384, 128, 32, 2), (150, 128, 32, 2), (1, 5, 3, 1), (4099, 300, 70, 10)])
+def test_readout_classifier_kernels_against_float64(native, F, h1, h2, c):
+    """LinearClassifier.forward of ONE graph (models/GNN.py:312-325) in one launch each way: logits, the saved hidden vectors and
+    all seven gradients against float64; replays give the same bits (the ticket counter is left at 0)."""
+    from graphnet_classifier_amd import functional as Fn
+    rng = np.random.default_rng(F + h1)
+    y = _t(rng.standard_normal(F)).requires_grad_()
+    params = [p.requires_grad_() for p in (*_lin(rng, h1, F), *_lin(rng, h2, h1), *_lin(rng, c, h2))]
+    logits = Fn.readout(y, *params)
+    yd = _D(y.detach()).requires_grad_()
+    pd = [_D(p.detach()).requires_grad_() for p in params]
+    ref = torch.relu(torch.relu(yd @ pd[0].t() + pd[1]) @ pd[2].t() + pd[3]) @ pd[4].t() + pd[5]
+    assert float((_D(logits.detach()) - ref.detach()).abs().max()) < TOL * max(1.0, float(ref.detach().abs().max()))
+    gl = _t(rng.standard_normal(c))
+    logits.backward(gl)
+    ref.backward(_D(gl))
+    for got, want in zip([y.grad] + [p.grad for p in params], [yd.grad] + [p.grad for p in pd]):
+        assert got.shape == want.shape
+        assert float((_D(got) - want).abs().max()) < TOL * max(1.0, float(want.abs().max()))
+    again = Fn.readout(y.detach(), *[p.detach() for p in params])
+    assert torch.equal(again, logits.detach())
