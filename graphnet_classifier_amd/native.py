@@ -586,8 +586,9 @@ _readout_tickets: dict = {}
 
 
 def _readout_ticket(dev) -> torch.Tensor:
-    """One zeroed device counter per device (every launch leaves it at 0)."""
-    key = str(dev)
+    """One zeroed device counter per device AND stream (every launch leaves it at 0; launches on one stream are ordered, launches
+    on different streams must not share a counter)."""
+    key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
     if key not in _readout_tickets:
         _readout_tickets[key] = torch.zeros(1, dtype=torch.int32, device=dev)
     return _readout_tickets[key]
