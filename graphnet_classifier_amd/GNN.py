@@ -262,9 +262,12 @@ class GraphNet(nn.Module):
 
     def forward_device(self, x: Tensor, pos: Tensor, topo: GraphTopology) -> Tensor:
         """GraphNet.forward on device tensors with a prepared topology (models/GNN.py:297-309)."""
-        edge_attr = Fn.edge_features(pos, topo.src_sorted, topo.dst_sorted)            # :299-302 (K6)
         out = self.node_encoder.forward_segments([(x.view(x.size(0), -1), None)])         # :305
-        edge_attr = self.edge_encoder.forward_segments([(edge_attr, None)])               # :306
+        # :299-302 + :306: K6 as the prologue of the edge encoder's launch where a kernel offers it (inference, large batches)
+        edge_attr = self.edge_encoder.forward_edge_features(pos, topo.src_sorted, topo.dst_sorted)
+        if edge_attr is None:
+            edge_attr = Fn.edge_features(pos, topo.src_sorted, topo.dst_sorted)           # :299-302 (K6)
+            edge_attr = self.edge_encoder.forward_segments([(edge_attr, None)])           # :306
         out, _ = self.graph_processor.forward_sorted(out, topo, edge_attr)                # :307
         out = self.node_decoder.forward_segments([(out, None)])                           # :308
         if topo.deferred:  # validation not read back yet: a bad edge_index must not yield a plausible result

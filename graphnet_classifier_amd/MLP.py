@@ -96,6 +96,18 @@ class MLP(nn.Module):
                 y = y + residual
         return y
 
+    def forward_edge_features(self, pos: Tensor, src: Tensor, dst: Tensor) -> Tensor | None:
+        """This MLP on the edge features of models/GNN.py:299-302 WITHOUT storing them (K6 as the launch's prologue); None
+        when that form is not available (training, BatchNorm, a shape / batch size no kernel serves this way)."""
+        lin = self._linears()
+        if self.activation_name != "ReLU" or isinstance(self.model[-1], nn.BatchNorm1d):
+            return None
+        if torch.is_grad_enabled() and (pos.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return None  # the backward needs the feature rows (dW_0)
+        norm = self.model[-1] if self.norm_type is not None else None
+        ln = (norm.weight, norm.bias, norm.eps) if isinstance(norm, nn.LayerNorm) else None
+        return native.mlp_forward_edge_features(pos, src, dst, [m.weight for m in lin], [m.bias for m in lin], ln=ln)
+
     def forward(self, x: Tensor):
         """models/MLP.py:45-47: flatten to (rows, -1), cast to float32, run the Sequential."""
         dev = require_gpu_param(self.model[0].weight, "MLP")

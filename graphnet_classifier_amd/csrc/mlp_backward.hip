@@ -1242,6 +1242,10 @@ extern "C" int gnc_mlp_backward_f32(const gnc_mlp_bwd_desc_t* bd, void* stream_)
   const gnc_mlp_desc_t& d = bd->fwd;
   int rc = validate_desc(&d, false);
   if (rc) return rc;
+  if (d.ef_pos) {  // the backward reads the segment's rows (dW_0): a training forward materialises them (gnc_edge_features_f32)
+    gnc::set_error("gnc_mlp_backward_f32: fwd.ef_pos (computed edge features) is an inference-only form");
+    return GNC_ERR_UNSUPPORTED;
+  }
   int nmm = 0, nadd = 0, T = 0;
   BwdPlan pl;
   if (bd->dw_partial[0]) {  // fused data + weight-gradient kernel

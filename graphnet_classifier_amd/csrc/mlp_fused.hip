@@ -348,6 +348,44 @@ extern "C" int gnc_mlp_save_act_supported(const gnc_mlp_desc_t* desc) {
   return GNC_OK;
 }
 
+// K6 prologue (gnc_mlp_desc_t.ef_pos, ABI 19): served by the weights-resident kernel, and not for a small batch (there the
+// column-split kernel on a materialised [rows, 3] table is the faster route)
+extern "C" int gnc_mlp_edge_features_supported(const gnc_mlp_desc_t* desc) {
+  int rc = validate_desc(desc, false);
+  if (rc) return rc;
+  const int L = desc->num_linear;
+  int T = tiles_for(desc->out_dim[0]);
+  const int od = desc->out_dim[L - 1];
+  const bool narrow_out = od <= 32;
+  if (!narrow_out && tiles_for(od) > T) T = tiles_for(od);
+  gnc_mlp_desc_t probe = *desc;
+  alignas(16) static float dummy_f[4];
+  static int32_t dummy_i[1];
+  if (!probe.ef_pos) probe.ef_pos = dummy_f;
+  if (!probe.ef_src) probe.ef_src = dummy_i;
+  if (!probe.ef_dst) probe.ef_dst = dummy_i;
+  bool ok = false;
+  {
+    gnc_mlp_desc_t plain = *desc;
+    plain.ef_pos = nullptr;
+    if (!plain.seg[0].ptr) plain.seg[0].ptr = dummy_f;
+    bool small = false;
+    rc = launch_col16(plain, nullptr, &small, true);
+    if (rc) return rc;
+    if (!small && desc->rows > 0) {
+      rc = launch_resident(probe, T, narrow_out, nullptr, &ok, true);
+      if (rc) return rc;
+    }
+  }
+  if (!ok) {
+    gnc::set_error("gnc_mlp_edge_features_supported: needs the edge encoder's shape on the weights-resident kernel (one computed "
+                   "segment of width 3 = space_dim 2, >= 2 Linear layers of widths 33..64, ReLU, no residual / save_act / agg_out) "
+                   "and a batch above the small-batch limit");
+    return GNC_ERR_UNSUPPORTED;
+  }
+  return GNC_OK;
+}
+
 // shape + alignment answer: 0 when the small-batch (column-split) kernel serves this description exactly as given - it is
 // the only kernel that reads tables and weights whose rows are not 16-B pieces (3-column inputs, [H, 3] weights) in place
 extern "C" int gnc_mlp_small_batch_supported(const gnc_mlp_desc_t* desc) {
@@ -377,6 +415,16 @@ extern "C" int gnc_mlp_forward_f32(const gnc_mlp_desc_t* desc, void* stream_) {
   if (!narrow_out && tiles_for(od) > T) T = tiles_for(od);
 
   bool launched = false;
+  if (desc->ef_pos) {  // K6 prologue (ABI 19): the weights-resident kernel only, and only where the query says so
+    rc = gnc_mlp_edge_features_supported(desc);
+    if (rc) return rc;
+    rc = launch_resident(*desc, T, narrow_out, stream, &launched);
+    if (!rc && !launched) {
+      gnc::set_error("gnc_mlp_forward_f32: ef_pos given but the weights-resident kernel did not take the launch");
+      rc = GNC_ERR_UNSUPPORTED;
+    }
+    return rc;
+  }
   rc = launch_col16(*desc, stream, &launched);  // small batches at 65..128 features: column-split workgroups
   if (rc || launched) return rc;
   rc = launch_resident(*desc, T, narrow_out, stream, &launched);  // weights-resident variant (decides by LDS fit)

@@ -84,7 +84,9 @@ constexpr int RNT = RWAVES * 64;
 // FULL: every width of the launch is exactly 64 (segments, hidden layers, output), three Linear layers, LayerNorm, vector
 // output rows - the c3 edge processor.  The general instance keeps ~40 loop-invariant lane masks (feature / column < width)
 // and the dimensions themselves alive across the tile loop; here they are compile-time constants.
-template <int HT, int OT, int NMM, int NADD, bool RESREG, bool AGG = false, bool SAVE = false, bool FULL = false>
+// EF: K6 as the prologue (gnc_mlp_desc_t.ef_pos): the rows of the only segment are computed from the positions of the
+// edge's endpoints (two coalesced id loads one tile ahead, two 8-B gathers per row and tile) instead of being read.
+template <int HT, int OT, int NMM, int NADD, bool RESREG, bool AGG = false, bool SAVE = false, bool FULL = false, bool EF = false>
 __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t d, const int num_wtiles,
                                                            const int total_chunks) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -192,10 +194,43 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
   f32x4 addA[NADD ? NP : 1], addB[NADD ? NP : 1];
   // row offsets of gathered segments: off0 = segment 0 of the NEXT tile, offs[s>=1] = segment s of the CURRENT tile
   uint32_t offs[NS];
-  load_rows(cur, sv[0], wt, row_offset(wt, sv[0]));
+  // EF: endpoint ids of the tile after next (lane & 31 = tile row), endpoint positions of the next tile
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  int ef_s = 0, ef_d = 0;
+  f32x2 ef_ps = {0.f, 0.f}, ef_pd = {0.f, 0.f};
+  const __amdgpu_buffer_rsrc_t ef_win =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(EF ? d.ef_pos : nullptr), 0, EF ? (int)(uint32_t)(d.ef_nodes * 8) : 0, 0x00020000);
+  auto ef_ids = [&](int t) {
+    const int tc = t < last_wt ? t : last_wt;
+    int r = tc * RPW + (lane & 31);
+    r = r < rows ? r : rows - 1;
+    ef_s = d.ef_src[r];
+    ef_d = d.ef_dst[r];
+  };
+  auto ef_fetch = [&]() {  // launcher: ef_nodes * 8 < 4 GiB; an id outside the table reads as (0, 0)
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    ef_ps = __builtin_bit_cast(f32x2, (u32x2)__builtin_amdgcn_raw_buffer_load_b64(ef_win, (uint32_t)ef_s * 8u, 0, 0));
+    ef_pd = __builtin_bit_cast(f32x2, (u32x2)__builtin_amdgcn_raw_buffer_load_b64(ef_win, (uint32_t)ef_d * 8u, 0, 0));
+  };
+  auto ef_stage = [&]() {  // [dx, dy, |dx| + |dy|, 0 | 0 0 0 0]: the 8 columns the first Linear's one k-group reads
+    compiler_lds_barrier();
+    const float dx = ef_pd.x - ef_ps.x, dy = ef_pd.y - ef_ps.y;
+    f32x4 v = {dx, dy, __builtin_fabsf(dx) + __builtin_fabsf(dy), 0.f};
+    if (h) v = f32x4{0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4*>(abuf + i * LDSW + 4 * h) = v;
+    compiler_lds_barrier();
+  };
+  uint32_t off0 = 0;
+  if constexpr (EF) {
+    ef_ids(wt);
+    ef_fetch();
+    ef_ids(wt + stride);
+  } else {
+    load_rows(cur, sv[0], wt, row_offset(wt, sv[0]));
+  }
 #pragma unroll
   for (int s = 1; s < NS; ++s) offs[s] = row_offset(wt, sv[s]);
-  uint32_t off0 = row_offset(wt + stride, sv[0]);
+  if constexpr (!EF) off0 = row_offset(wt + stride, sv[0]);
 
   const int col_out = c4 * 4;
   const bool vec_out = FULL || ((out_dim % 4 == 0) && (d.ld_out % 4 == 0) && ((reinterpret_cast<uintptr_t>(d.out) & 15u) == 0));
@@ -228,7 +263,8 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
 #pragma unroll
     for (int s = 0; s < NMM; ++s) {
       bool interleaved = false;
-      stage(cur, sv[s].width);
+      if constexpr (EF) ef_stage();
+      else stage(cur, sv[s].width);
       PROBE(0);  // wait for the step's rows + staging
       // request what comes next before the MFMAs of this step start
       if (s + 1 < NMM) {
@@ -277,6 +313,9 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
             offs[NMM] = row_offset(nwt, sv[NMM]);
             offs[NMM + 1] = row_offset(nwt, sv[NMM + 1]);
           }
+        } else if constexpr (EF) {
+          ef_fetch();  // the next tile's endpoints (ids fetched one tile ago), then the ids of the tile after it
+          ef_ids(nwt + stride);
         } else {
           load_rows(cur, sv[0], nwt, off0);
           off0 = row_offset(nwt + stride, sv[0]);
@@ -401,8 +440,12 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
     // The compiler's counted vmcnt waits do not know about the asm stores below; make it collect the
     // next tile's prefetched rows (issued >= one Linear ago) BEFORE the stores join the queue, so that
     // no later wait for them has to sit out the stores as well.
+    if constexpr (EF) {
+      asm volatile("" ::"v"(ef_ps), "v"(ef_pd), "v"(ef_s), "v"(ef_d));
+    } else {
 #pragma unroll
-    for (int p = 0; p < NP; ++p) asm volatile("" ::"v"(cur[p]));
+      for (int p = 0; p < NP; ++p) asm volatile("" ::"v"(cur[p]));
+    }
     // ... and the gather ids fetched for the next tile: their first use comes after the stores, where a wait for
     // them (vmcnt is in order) would sit out the stores' HBM round trip
 #pragma unroll
@@ -455,12 +498,12 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
   PROBE_END();
 }
 
-template <int HT, int OT, int NMM, int NADD, bool RESREG, bool AGG = false, bool SAVE = false, bool FULL = false>
+template <int HT, int OT, int NMM, int NADD, bool RESREG, bool AGG = false, bool SAVE = false, bool FULL = false, bool EF = false>
 int launch(const gnc_mlp_desc_t& d, int total_chunks, size_t smem, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
     int rc = gnc::check_hip(
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_resident_kernel<HT, OT, NMM, NADD, RESREG, AGG, SAVE, FULL>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_resident_kernel<HT, OT, NMM, NADD, RESREG, AGG, SAVE, FULL, EF>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
         "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc) return rc;
@@ -470,7 +513,7 @@ int launch(const gnc_mlp_desc_t& d, int total_chunks, size_t smem, hipStream_t s
   int64_t grid = gnc::ceil_div(num_wtiles, RWAVES);
   if (grid > gnc::num_cu()) grid = gnc::num_cu();  // one persistent workgroup per CU
   if constexpr (AGG) grid = gnc::num_cu();        // agg_fix has two entries for every wave of the full grid
-  mlp_resident_kernel<HT, OT, NMM, NADD, RESREG, AGG, SAVE, FULL>
+  mlp_resident_kernel<HT, OT, NMM, NADD, RESREG, AGG, SAVE, FULL, EF>
       <<<dim3((unsigned)grid), dim3(RNT), smem, stream>>>(d, (int)num_wtiles, total_chunks);
   return gnc::check_launch("mlp_resident_kernel");
 }
@@ -494,6 +537,7 @@ int gnc_mlp::launch_resident(const gnc_mlp_desc_t& d, int T, bool narrow_out, hi
   int nmm = 0, nadd = 0;
   for (int s = 0; s < d.num_segments; ++s) {
     const gnc_mlp_segment_t& g = d.seg[s];
+    if (d.ef_pos && s == 0) continue;  // computed rows: nothing is read through this segment's table
     if (g.width > KC || g.ld % 4 != 0 || !al16(g.ptr)) return GNC_OK;
     // gathers go through a buffer window over the whole table: its size must be stated and below 4 GiB
     if (g.index && (g.table_rows <= 0 || g.table_rows * (int64_t)g.ld * 4 > 0xffffffffll)) return GNC_OK;
@@ -503,6 +547,13 @@ int gnc_mlp::launch_resident(const gnc_mlp_desc_t& d, int T, bool narrow_out, hi
       if (nadd) return GNC_OK;  // a MATMUL segment after an ADD one
       ++nmm;
     }
+  }
+  if (d.ef_pos) {  // K6 prologue: the edge encoder's shape only (one computed segment, no residual, inference)
+    ++nmm;
+    const gnc_mlp_segment_t& g = d.seg[0];
+    if (d.num_segments != 1 || g.mode != GNC_SEG_MATMUL || g.index || d.ef_space_dim != 2 || g.width != 3 || !d.ef_src || !d.ef_dst ||
+        d.ef_nodes <= 0 || d.ef_nodes * 8 > 0xffffffffll || d.residual || d.save_act[0] || d.agg_out || narrow_out || L < 2 || T != 2)
+      return GNC_OK;
   }
   if (nmm < 1 || nmm > 3 || (nadd != 0 && !(nadd == 2 && nmm == 1))) return GNC_OK;
   if (d.residual && (d.ld_residual % 4 != 0 || !al16(d.residual))) return GNC_OK;
@@ -527,6 +578,11 @@ int gnc_mlp::launch_resident(const gnc_mlp_desc_t& d, int T, bool narrow_out, hi
   bool full64 = !no_full && L == 3 && od == KC && d.ln_gamma && d.ld_out % 4 == 0 && al16(d.out);
   for (int s = 0; s < d.num_segments; ++s) full64 = full64 && d.seg[s].width == KC;
   for (int l = 0; l < L; ++l) full64 = full64 && d.out_dim[l] == KC && (l == 0 || d.in_dim[l] == KC);
+  if (d.ef_pos) {
+    *launched = true;
+    if (probe_only) return GNC_OK;
+    return launch<2, 2, 1, 0, false, false, false, false, true>(d, total_chunks, smem, stream);
+  }
   if (d.save_act[0]) {
     // training forward: SAVE instances exist for the shapes whose K8 kernel reads the saved tensors (the fused data +
     // weight-gradient kernel: widths 33..64, ONE row-ordered MATMUL segment, 0 or 2 gathered ADD segments)

@@ -14,7 +14,7 @@
 //
 // Anything the LDS path cannot take (a range longer than 4096 edges, i.e. a graph with more than 2048 edges or an
 // edge list that is not graph-ordered; a destination span above 4096 nodes) raises a DEVICE flag
-// (status[2]); the general path - a stable LSD radix sort written for this file, every kernel of which returns at once
+// (status[2]); the general path - a stable LSD radix sort written for this file, ONE kernel that returns at once
 // unless the flag is set - is enqueued behind it, so the call never needs the host to look at the flag (capturable, no
 // sync).  Callers that synchronise anyway may pass gated_fallback = 0 and run gnc_csr_build (rocPRIM) when they see the flag.
 #include <stdlib.h>
@@ -80,8 +80,9 @@ __global__ __launch_bounds__(NT) void topo_tile_minmax(const IdxT* __restrict__ 
 
 // ---- pass B (one workgroup): P[t] = max over tiles before t (-1), S[t] = min over tiles after t (IMAX)
 __global__ __launch_bounds__(1024) void topo_tile_scan(const int* __restrict__ tmin, const int* __restrict__ tmax, int num_tiles,
-                                                       int* __restrict__ P, int* __restrict__ S) {
+                                                       int* __restrict__ P, int* __restrict__ S, unsigned* __restrict__ fb_bar) {
   __shared__ int cmax[1024], cmin[1024];
+  if (fb_bar && threadIdx.x == 0) *fb_bar = 0;  // arrival counter of the general path's grid barrier
   const int per = (num_tiles + 1023) / 1024;
   const int t0 = threadIdx.x * per, t1 = t0 + per < num_tiles ? t0 + per : num_tiles;
   int mx = -1, mn = IMAX;
@@ -352,9 +353,16 @@ __global__ __launch_bounds__(NT) void topo_tile_sort(const IdxT* __restrict__ ds
   if (bad_src) status[1] = 1;
 }
 
-// ---- general path: stable LSD radix sort, 8-bit digits, every kernel gated by status[2] -------------------------------
+// ---- general path: stable LSD radix sort, 8-bit digits, ONE kernel gated by status[2] ---------------------------------
+// The LDS path enqueues this kernel behind itself on every call (no host look at the flag: capturable), so what it costs
+// when the flag is NOT set matters: one launch that returns at once (the first version was 11 gated launches per call, 50 us
+// of dispatch at c3).  When the flag IS set the passes of the sort are separated by a grid barrier: the grid is at most two
+// one-wave workgroups per CU (64 KB of LDS each), i.e. every workgroup is resident, and the barrier gives up after
+// FB_TIMEOUT ticks of the 100 MHz clock (status[2] = 2, status[0] = 1: every caller's validity check fails loudly) rather
+// than spin for ever if that assumption is ever broken.
 constexpr int FB_NT = 64;       // one wave per block: cnt[256][64] counters in LDS
-constexpr int FB_MAXB = 512;    // blocks (= chunks of the list); every one of them is launched (and returns at once) on the LDS path too
+constexpr int FB_MAXB = 512;    // blocks (= chunks of the list)
+constexpr unsigned long long FB_TIMEOUT = 500000000ull;  // 5 s
 
 struct FbGeom {
   int nblocks;
@@ -365,116 +373,148 @@ struct FbGeom {
 FbGeom fb_geom(int64_t E) {
   FbGeom g;
   int64_t nb = (E + 4095) / 4096;
-  g.nblocks = (int)(nb < 1 ? 1 : (nb > FB_MAXB ? FB_MAXB : nb));
+  int64_t cap = (int64_t)gnc::num_cu() * 2;  // co-resident: the grid barrier needs every block on the chip
+  cap = cap < FB_MAXB ? cap : FB_MAXB;
+  g.nblocks = (int)(nb < 1 ? 1 : (nb > cap ? cap : nb));
   g.chunk = (int)((E + g.nblocks - 1) / g.nblocks);
   g.run = (g.chunk + FB_NT - 1) / FB_NT;
   return g;
 }
 
-template <typename IdxT>
-__global__ void fb_prepare(const int* __restrict__ gate, const IdxT* __restrict__ dst, int64_t E, int64_t N, unsigned* __restrict__ keys,
-                           int* __restrict__ vals, int* __restrict__ status) {
-  if (*gate == 0) return;
-  bool bad = false;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
-    keys[e] = (unsigned)checked_id(dst[e], N, &bad);
-    vals[e] = (int)e;
-  }
-  if (bad) status[0] = 1;
-}
-
-__device__ __forceinline__ void fb_count(unsigned (*cnt)[FB_NT], const unsigned* keys, int64_t E, FbGeom g, int shift) {
-  for (int d = 0; d < 256; ++d) cnt[d][threadIdx.x] = 0;
-  const int64_t e0 = (int64_t)blockIdx.x * g.chunk + (int64_t)threadIdx.x * g.run;
-  int64_t e1 = e0 + g.run, cend = ((int64_t)blockIdx.x + 1) * g.chunk;
-  e1 = e1 < cend ? e1 : cend;
-  e1 = e1 < E ? e1 : E;
-  for (int64_t e = e0; e < e1; ++e) ++cnt[(keys[e] >> shift) & 255u][threadIdx.x];
-}
-
-__global__ __launch_bounds__(FB_NT) void fb_hist(const int* __restrict__ gate, const unsigned* __restrict__ keys, int64_t E, FbGeom g,
-                                                 int shift, unsigned* __restrict__ tab) {
-  if (*gate == 0) return;
-  __shared__ unsigned cnt[256][FB_NT];
-  fb_count(cnt, keys, E, g, shift);
-  __syncthreads();
-  for (int d = threadIdx.x; d < 256; d += FB_NT) {
-    unsigned s = 0;
-    for (int k = 0; k < FB_NT; ++k) s += cnt[d][k];
-    tab[(int64_t)d * g.nblocks + blockIdx.x] = s;  // digit-major: the scan order of an LSD pass
-  }
-}
-
-__global__ __launch_bounds__(1024) void fb_scan(const int* __restrict__ gate, unsigned* __restrict__ tab, int n) {
-  if (*gate == 0) return;
-  __shared__ unsigned part[1024];
-  const int per = (n + 1023) / 1024;
-  const int i0 = threadIdx.x * per, i1 = i0 + per < n ? i0 + per : n;
-  unsigned s = 0;
-  for (int k = i0; k < i1; ++k) s += tab[k];
-  part[threadIdx.x] = s;
+// every block arrives once per barrier; the counter only grows (zeroed by topo_tile_scan in front of the sort kernels)
+__device__ __forceinline__ bool fb_grid_barrier(unsigned* bar, unsigned target) {
+  __shared__ int ok_s;
+  __threadfence();
   __syncthreads();
   if (threadIdx.x == 0) {
-    unsigned run = 0;
-    for (int k = 0; k < 1024; ++k) {
-      const unsigned v = part[k];
-      part[k] = run;
-      run += v;
+    __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long t0 = wall_clock64();
+    int ok = 1;
+    while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(16);
+      if (wall_clock64() - t0 > FB_TIMEOUT) {
+        ok = 0;
+        break;
+      }
     }
+    ok_s = ok;
   }
   __syncthreads();
-  unsigned run = part[threadIdx.x];
-  for (int k = i0; k < i1; ++k) {
-    const unsigned v = tab[k];
-    tab[k] = run;
-    run += v;
-  }
-}
-
-__global__ __launch_bounds__(FB_NT) void fb_scatter(const int* __restrict__ gate, const unsigned* __restrict__ keys,
-                                                    const int* __restrict__ vals, int64_t E, FbGeom g, int shift,
-                                                    const unsigned* __restrict__ tab, unsigned* __restrict__ keys_out,
-                                                    int* __restrict__ vals_out) {
-  if (*gate == 0) return;
-  __shared__ unsigned cnt[256][FB_NT];
-  fb_count(cnt, keys, E, g, shift);
-  __syncthreads();
-  for (int d = threadIdx.x; d < 256; d += FB_NT) {  // first output slot of (digit d, thread k): stable in list order
-    unsigned run = tab[(int64_t)d * g.nblocks + blockIdx.x];
-    for (int k = 0; k < FB_NT; ++k) {
-      const unsigned c = cnt[d][k];
-      cnt[d][k] = run;
-      run += c;
-    }
-  }
-  __syncthreads();
-  const int64_t e0 = (int64_t)blockIdx.x * g.chunk + (int64_t)threadIdx.x * g.run;
-  int64_t e1 = e0 + g.run, cend = ((int64_t)blockIdx.x + 1) * g.chunk;
-  e1 = e1 < cend ? e1 : cend;
-  e1 = e1 < E ? e1 : E;
-  for (int64_t e = e0; e < e1; ++e) {
-    const unsigned k = keys[e];
-    const unsigned pos = cnt[(k >> shift) & 255u][threadIdx.x]++;
-    keys_out[pos] = k;
-    vals_out[pos] = vals[e];
-  }
+  __threadfence();
+  return ok_s != 0;
 }
 
 template <typename IdxT, bool WITH_ENDPOINTS>
-__global__ void fb_finish(const int* __restrict__ gate, const unsigned* __restrict__ keys, const int* __restrict__ vals,
-                          const IdxT* __restrict__ src, int64_t E, int64_t N, int* __restrict__ rowptr, int* __restrict__ perm,
-                          int* __restrict__ src_sorted, int* __restrict__ dst_sorted, int* __restrict__ status) {
+__global__ __launch_bounds__(FB_NT) void fb_sort_all(const int* gate, const IdxT* dst, const IdxT* src, int64_t E, int64_t N, FbGeom g,
+                                                     int bits, unsigned* keys_a, unsigned* keys_b, int* vals_a, int* vals_b,
+                                                     unsigned* tab, unsigned* part, unsigned* bar, int* rowptr, int* perm,
+                                                     int* src_sorted, int* dst_sorted, int* status) {
   if (*gate == 0) return;
+  __shared__ unsigned cnt[256][FB_NT];
+  const int tid = threadIdx.x, blk = blockIdx.x, nb = g.nblocks;
+  const int64_t gtid = (int64_t)blk * FB_NT + tid, gsz = (int64_t)nb * FB_NT;
+  unsigned arrivals = 0;
+#define FB_BARRIER()                                         \
+  do {                                                       \
+    arrivals += (unsigned)nb;                                \
+    if (!fb_grid_barrier(bar, arrivals)) {                   \
+      if (tid == 0) {                                        \
+        status[2] = 2;                                       \
+        status[0] = 1;                                       \
+      }                                                      \
+      return;                                                \
+    }                                                        \
+  } while (0)
+  {  // keys = validated destinations, values = edge ids
+    bool bad = false;
+    for (int64_t e = gtid; e < E; e += gsz) {
+      keys_a[e] = (unsigned)checked_id(dst[e], N, &bad);
+      vals_a[e] = (int)e;
+    }
+    if (bad) status[0] = 1;
+  }
+  FB_BARRIER();
+  unsigned *ka = keys_a, *kb = keys_b;
+  int *va = vals_a, *vb = vals_b;
+  const int64_t e0 = (int64_t)blk * g.chunk + (int64_t)tid * g.run;
+  int64_t e1 = e0 + g.run;
+  {
+    const int64_t cend = ((int64_t)blk + 1) * g.chunk;
+    e1 = e1 < cend ? e1 : cend;
+    e1 = e1 < E ? e1 : E;
+  }
+  for (int shift = 0; shift < bits; shift += 8) {
+    // (1) per-thread digit counts of this block's chunk (kept in LDS for the placement), per-block totals digit-major
+    for (int d = 0; d < 256; ++d) cnt[d][tid] = 0;
+    for (int64_t e = e0; e < e1; ++e) ++cnt[(ka[e] >> shift) & 255u][tid];
+    __syncthreads();
+    for (int d = tid; d < 256; d += FB_NT) {
+      unsigned s = 0;
+      for (int k = 0; k < FB_NT; ++k) s += cnt[d][k];
+      tab[(int64_t)d * nb + blk] = s;  // digit-major: the scan order of an LSD pass
+    }
+    FB_BARRIER();
+    // (2) exclusive scan of the 256 * nb totals: block b owns entries [256 b, 256 b + 256); slice totals first ...
+    unsigned v[4], incl[4];
+    {
+      unsigned run = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[j] = tab[(int64_t)blk * 256 + j * 64 + tid];
+        unsigned x = v[j];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const unsigned a = __shfl_up(x, o, 64);
+          if (tid >= o) x += a;
+        }
+        incl[j] = x + run;
+        run += __shfl(x, 63, 64);
+      }
+      if (tid == 0) part[blk] = run;
+    }
+    FB_BARRIER();
+    // ... then every block adds the totals of the slices in front of its own and writes its slice back
+    {
+      unsigned off = 0;
+      for (int b = tid; b < blk; b += FB_NT) off += part[b];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) off += __shfl_xor(off, o, 64);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tab[(int64_t)blk * 256 + j * 64 + tid] = off + incl[j] - v[j];
+    }
+    FB_BARRIER();
+    // (3) placement: first output slot of (digit d, thread k) - stable in list order
+    for (int d = tid; d < 256; d += FB_NT) {
+      unsigned run = tab[(int64_t)d * nb + blk];
+      for (int k = 0; k < FB_NT; ++k) {
+        const unsigned c = cnt[d][k];
+        cnt[d][k] = run;
+        run += c;
+      }
+    }
+    __syncthreads();
+    for (int64_t e = e0; e < e1; ++e) {
+      const unsigned k = ka[e];
+      const unsigned pos = cnt[(k >> shift) & 255u][tid]++;
+      kb[pos] = k;
+      vb[pos] = va[e];
+    }
+    FB_BARRIER();
+    unsigned* tk = ka; ka = kb; kb = tk;
+    int* tv = va; va = vb; vb = tv;
+  }
+#undef FB_BARRIER
+  // row pointers from the boundaries of the sorted keys, permutation, permuted endpoints
   bool bad = false;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= E; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t prev = i == 0 ? -1 : (int64_t)keys[i - 1];
-    const int64_t cur = i == E ? N : (int64_t)keys[i];
-    for (int64_t v = prev + 1; v <= cur; ++v) rowptr[v] = (int)i;
+  for (int64_t i = gtid; i <= E; i += gsz) {
+    const int64_t prev = i == 0 ? -1 : (int64_t)ka[i - 1];
+    const int64_t cur = i == E ? N : (int64_t)ka[i];
+    for (int64_t q = prev + 1; q <= cur; ++q) rowptr[q] = (int)i;
     if (i < E) {
-      perm[i] = vals[i];
+      perm[i] = va[i];
       if constexpr (WITH_ENDPOINTS) {
-        dst_sorted[i] = (int)keys[i];
-        src_sorted[i] = checked_id(src[vals[i]], N, &bad);
+        dst_sorted[i] = (int)ka[i];
+        src_sorted[i] = checked_id(src[va[i]], N, &bad);
       }
     }
   }
@@ -492,7 +532,7 @@ unsigned key_bits(int64_t n) {  // bits of the largest key, n - 1
 
 struct Workspace {
   int *tmin, *tmax, *P, *S;
-  unsigned *keys_a, *keys_b, *tab;
+  unsigned *keys_a, *keys_b, *tab, *part, *bar;
   int *vals_a, *vals_b;
   size_t bytes;
 };
@@ -507,7 +547,7 @@ Workspace carve(void* base_, int64_t E, bool fallback) {
   w.tmax = reinterpret_cast<int*>(take((size_t)tiles * 4));
   w.P = reinterpret_cast<int*>(take((size_t)tiles * 4));
   w.S = reinterpret_cast<int*>(take((size_t)tiles * 4));
-  w.keys_a = w.keys_b = w.tab = nullptr;
+  w.keys_a = w.keys_b = w.tab = w.part = w.bar = nullptr;
   w.vals_a = w.vals_b = nullptr;
   if (fallback) {
     w.keys_a = reinterpret_cast<unsigned*>(take((size_t)E * 4));
@@ -515,6 +555,8 @@ Workspace carve(void* base_, int64_t E, bool fallback) {
     w.vals_a = reinterpret_cast<int*>(take((size_t)E * 4));
     w.vals_b = reinterpret_cast<int*>(take((size_t)E * 4));
     w.tab = reinterpret_cast<unsigned*>(take((size_t)256 * FB_MAXB * 4));
+    w.part = reinterpret_cast<unsigned*>(take((size_t)FB_MAXB * 4));
+    w.bar = reinterpret_cast<unsigned*>(take(4));
   }
   w.bytes = (size_t)(p - p0) + kAlign;
   return w;
@@ -535,7 +577,7 @@ int build(const IdxT* src, const IdxT* dst, int64_t E, int64_t N, int* rowptr, i
   topo_tile_minmax<IdxT><<<tiles, NT, 0, stream>>>(dst, E, N, w.tmin, w.tmax, status);
   rc = gnc::check_launch("topo_tile_minmax");
   if (rc) return rc;
-  topo_tile_scan<<<1, 1024, 0, stream>>>(w.tmin, w.tmax, tiles, w.P, w.S);
+  topo_tile_scan<<<1, 1024, 0, stream>>>(w.tmin, w.tmax, tiles, w.P, w.S, w.bar);
   rc = gnc::check_launch("topo_tile_scan");
   if (rc) return rc;
   const char* pl = getenv("GNC_TOPO_PHASE_LIMIT");  // developer probe: stop the sort kernel after phase n (timing only)
@@ -543,26 +585,11 @@ int build(const IdxT* src, const IdxT* dst, int64_t E, int64_t N, int* rowptr, i
                                                                status, pl ? atoi(pl) : 0);
   rc = gnc::check_launch("topo_tile_sort");
   if (rc || !gated_fallback) return rc;
-  // general path, gated on the device by status[2]
-  const int* gate = status + 2;
+  // general path, gated on the device by status[2]: one launch
   const FbGeom g = fb_geom(E);
-  int64_t pb = gnc::ceil_div(E, 256);
-  const int64_t cap = gnc::num_cu() * 2;  // grid-stride kernels: a small grid keeps the gated launches of the LDS path cheap
-  pb = pb < cap ? pb : cap;
-  fb_prepare<IdxT><<<(unsigned)pb, 256, 0, stream>>>(gate, dst, E, N, w.keys_a, w.vals_a, status);
-  unsigned *ka = w.keys_a, *kb = w.keys_b;
-  int *va = w.vals_a, *vb = w.vals_b;
-  const int bits = (int)key_bits(N);
-  for (int shift = 0; shift < bits; shift += 8) {
-    fb_hist<<<g.nblocks, FB_NT, 0, stream>>>(gate, ka, E, g, shift, w.tab);
-    fb_scan<<<1, 1024, 0, stream>>>(gate, w.tab, 256 * g.nblocks);
-    fb_scatter<<<g.nblocks, FB_NT, 0, stream>>>(gate, ka, va, E, g, shift, w.tab, kb, vb);
-    unsigned* tk = ka; ka = kb; kb = tk;
-    int* tv = va; va = vb; vb = tv;
-  }
-  int64_t fbk = gnc::ceil_div(E + 1, 256);
-  fbk = fbk < cap ? fbk : cap;
-  fb_finish<IdxT, WITH_ENDPOINTS><<<(unsigned)fbk, 256, 0, stream>>>(gate, ka, va, src, E, N, rowptr, perm, src_sorted, dst_sorted, status);
+  fb_sort_all<IdxT, WITH_ENDPOINTS><<<g.nblocks, FB_NT, 0, stream>>>(status + 2, dst, src, E, N, g, (int)key_bits(N), w.keys_a, w.keys_b,
+                                                                  w.vals_a, w.vals_b, w.tab, w.part, w.bar, rowptr, perm, src_sorted,
+                                                                  dst_sorted, status);
   return gnc::check_launch("gnc_topology_build(general path)");
 }
 

@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 GNC_MAX_SEGMENTS = 4
 GNC_MAX_LINEAR = 8
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 ACTIVATIONS = {  # nn.<Name> accepted by the reference's MLP(activation=...) (models/MLP.py:21)
     "ReLU": 0, "Identity": 1, "Tanh": 2, "Sigmoid": 3, "SiLU": 4, "GELU": 5, "LeakyReLU": 6, "ELU": 7,
@@ -30,6 +30,7 @@ _SIGNATURES = {
     "gnc_last_error_string": (c_char_p, []),
     "gnc_target_arch": (c_char_p, []),
     "gnc_mlp_agg_supported": (c_int32, [c_void_p]),
+    "gnc_mlp_edge_features_supported": (c_int32, [c_void_p]),
     "gnc_mlp_save_act_supported": (c_int32, [c_void_p]),
     "gnc_mlp_agg_fix_len": (c_int32, []),
     "gnc_mlp_small_batch_supported": (c_int32, [c_void_p]),
@@ -113,6 +114,7 @@ class MlpDesc(Structure):
         ("rows", c_int64),
         ("agg_out", c_void_p), ("ld_agg", c_int32), ("agg_index", c_void_p), ("agg_fix", c_void_p),
         ("save_act", c_void_p * GNC_MAX_LINEAR),
+        ("ef_pos", c_void_p), ("ef_src", c_void_p), ("ef_dst", c_void_p), ("ef_nodes", c_int64), ("ef_space_dim", c_int32),
     ]
 
 
@@ -579,6 +581,43 @@ def mlp_forward(segments, weights, biases, ln=None, activation: str = "ReLU", ac
             _check(lib.gnc_agg_fixup_f32(out.data_ptr(), _ld(out), rowptr.data_ptr(), fix.data_ptr(), fix.numel(), num_nodes,
                                          out.size(1), agg.data_ptr(), _ld(agg), _stream(out)), "gnc_agg_fixup_f32")
     return (out, agg) if aggregate is not None else out
+
+
+FOLD_EDGE_FEATURES = os.environ.get("GNC_NO_K6_FOLD") is None  # A/B switch: K6 as its own launch + a [E, 4] table
+
+
+def mlp_forward_edge_features(pos: torch.Tensor, src: torch.Tensor, dst: torch.Tensor, weights, biases, ln=None,
+                              activation: str = "ReLU", act_param: float = 0.0):
+    """The edge encoder on edge features that are never stored (models/GNN.py:299-302 feeding :306): K6 runs as the
+    prologue of the K4 launch (gnc_mlp_desc_t.ef_pos, ABI 19).  ``pos`` [N, 2] fp32, ``src`` / ``dst`` int32 [E] (the
+    topology's sorted endpoint vectors).  Inference only.  Returns None when no kernel serves the shape this way
+    (gnc_mlp_edge_features_supported): the caller then runs ``edge_features`` + ``mlp_forward``; bit-identical either way."""
+    lib = load_library()
+    if not FOLD_EDGE_FEATURES or pos.dim() != 2 or pos.size(1) != 2 or src.numel() == 0:
+        return None
+    _require_cuda(pos, src, dst)
+    if src.dtype != torch.int32 or dst.dtype != torch.int32:
+        raise TypeError("edge endpoint ids must be int32")
+    pos = pos.float().contiguous()
+    src, dst = src.contiguous(), dst.contiguous()
+    rows, sd = src.numel(), pos.size(1)
+    if weights[0].size(1) != sd + 1 or rows <= _small_batch_rows(lib):
+        return None
+    weights = [_vector_rows(_rowmajor(w.detach())) for w in weights]
+    biases = [b.contiguous() if b is not None else None for b in biases]
+    dev = pos.device
+    out = torch.empty(rows, weights[-1].size(0), dtype=torch.float32, device=dev)
+    desc = make_mlp_desc([(pos, None, sd + 1, SEG_MATMUL, 0)], weights, biases, ln, activation, act_param, None, out, rows)
+    desc.seg[0].ld = 4  # the segment's table is never read (computed rows); ld only has to cover the width
+    desc.ef_pos, desc.ef_src, desc.ef_dst = pos.data_ptr(), src.data_ptr(), dst.data_ptr()
+    desc.ef_nodes, desc.ef_space_dim = pos.size(0), sd
+    if lib.gnc_mlp_edge_features_supported(ctypes.byref(desc)) != 0:
+        return None
+    flops = 2.0 * rows * sum(w.size(0) * w.size(1) for w in weights)
+    with torch.cuda.device(dev):
+        _check(_launch(f"mlp_fused_in{weights[0].size(1)}_h{weights[0].size(0)}_out{weights[-1].size(0)}_L{len(weights)}", out,
+                       lambda: lib.gnc_mlp_forward_f32(ctypes.byref(desc), _stream(out)), flops), "gnc_mlp_forward_f32")
+    return out
 
 
 READOUT_MAX_HIDDEN, READOUT_MAX_CLASSES = 1024, 64

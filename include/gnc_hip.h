@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GNC_ABI_VERSION 18
+#define GNC_ABI_VERSION 19
 
 enum {
   GNC_OK = 0,
@@ -219,6 +219,21 @@ typedef struct gnc_mlp_desc {
    * models/MLP.py:45-47), so that gnc_mlp_backward_f32 can read it (act_given) instead of recomputing the forward of
    * every tile.  All of them or none; only where gnc_mlp_save_act_supported() says so. */
   float* save_act[GNC_MAX_LINEAR];
+  /* ABI 19, K6 as the prologue of the edge encoder (models/GNN.py:299-302 feeding :306).  ef_pos = NULL: off.
+   * With ef_pos set, the rows of segment 0 - the only segment: MATMUL, index NULL, width = ef_space_dim + 1, its ptr / ld
+   * ignored - are COMPUTED by the launch instead of read:
+   *   row r = [ pos[ef_dst[r]] - pos[ef_src[r]] , sum_d |pos[ef_dst[r]][d] - pos[ef_src[r]][d]| ]
+   * (the differences summed in dimension order starting from the first: bit for bit what gnc_edge_features_f32 stores), so
+   * the [rows, space_dim + 1] table never exists in HBM.  pos [ef_nodes, ef_space_dim] contiguous; an id outside
+   * [0, ef_nodes) reads as a zero position, never a fault.  Inference only (no save_act, no agg_out); served where
+   * gnc_mlp_edge_features_supported() says so (the weights-resident kernel, ef_space_dim = 2, hidden widths <= 64, a batch
+   * above the small-batch limit); gnc_mlp_forward_f32 returns GNC_ERR_UNSUPPORTED otherwise and the caller runs
+   * gnc_edge_features_f32 + a plain segment. */
+  const float* ef_pos;
+  const int32_t* ef_src;
+  const int32_t* ef_dst;
+  int64_t ef_nodes;
+  int32_t ef_space_dim;
 } gnc_mlp_desc_t;
 
 /* 0 if gnc_mlp_forward_f32 can run this description, GNC_ERR_UNSUPPORTED otherwise
@@ -230,6 +245,8 @@ int gnc_mlp_forward_f32(const gnc_mlp_desc_t* desc /* host */, void* stream);
 /* fused aggregation epilogue: 0 if this description can run with agg_out set (shape fields only) */
 int gnc_mlp_agg_supported(const gnc_mlp_desc_t* desc /* host */);
 int gnc_mlp_agg_fix_len(void); /* entries of agg_fix (2 per wave of the persistent grid) */
+/* ABI 19: 0 if gnc_mlp_forward_f32 serves this description with ef_pos set (pointer fields: alignment tests only) */
+int gnc_mlp_edge_features_supported(const gnc_mlp_desc_t* desc /* host */);
 /* ABI 18.  0 if the small-batch kernel (one 16-row tile per workgroup, the waves split the output features; rows up to
  * 128 x the number of CUs, widths 65..128, ReLU) serves this description EXACTLY AS GIVEN: it is the only kernel that reads
  * tables and weights whose rows are not 16-B pieces (the reference's [N, 3] inputs and nn.Linear(3, H) weights,

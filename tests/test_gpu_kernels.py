@@ -272,6 +272,52 @@ def test_edge_features(native, space_dim):
     assert torch.equal(out.cpu()[:, :space_dim], ref[:, :space_dim])
 
 
+@pytest.mark.parametrize("hidden,out_dim,hl,ln", [(64, 64, 2, True), (64, 64, 2, False), (48, 40, 2, True), (32, 48, 1, True), (64, 64, 3, True)])
+@pytest.mark.parametrize("rows", [40000, 33 * 1024 + 17])
+def test_edge_encoder_with_k6_as_its_prologue_is_bit_identical(native, hidden, out_dim, hl, ln, rows):
+    """ABI 19 (gnc_mlp_desc_t.ef_pos): the edge encoder computing models/GNN.py:299-302 inside its own launch gives, bit for
+    bit, what gnc_edge_features_f32 + the plain launch give (and that pair is checked against the oracle above / below);
+    row counts with a ragged last tile and fewer tiles than waves."""
+    rng = np.random.default_rng(rows + hidden)
+    n = 5003
+    pos = torch.from_numpy((rng.random((n, 2)) * 32).astype(np.float32)).to(DEV)
+    src = torch.from_numpy(rng.integers(0, n, size=rows).astype(np.int32)).to(DEV)
+    dst = torch.from_numpy(rng.integers(0, n, size=rows).astype(np.int32)).to(DEV)
+    sd = _mlp_sd(rng, 3, hidden, out_dim, hl, ln)
+    keys = sorted(sd, key=lambda k: (int(k.split(".")[2]), k))
+    lin = [(sd[k].to(DEV), sd[k.replace("weight", "bias")].to(DEV)) for k in keys if k.endswith("weight") and sd[k].dim() == 2]
+    lnp = None
+    if ln:
+        last = max(int(k.split(".")[2]) for k in sd)
+        lnp = (sd[f"m.model.{last}.weight"].to(DEV), sd[f"m.model.{last}.bias"].to(DEV), 1e-5)
+    ws, bs = [w for w, _ in lin], [b for _, b in lin]
+    ea = native.edge_features(pos, src, dst)
+    ref = native.mlp_forward([(ea, None)], ws, bs, ln=lnp)
+    got = native.mlp_forward_edge_features(pos, src, dst, ws, bs, ln=lnp)
+    assert got is not None, "the weights-resident kernel should serve this shape"
+    assert torch.equal(got, ref)
+    # against the oracle too (the reference's arithmetic on the reference's features)
+    ei = torch.stack([src.long().cpu(), dst.long().cpu()])
+    assert max_abs(got.cpu(), O.mlp_forward(sd, "m", O.edge_features(pos.cpu(), ei))) <= 1e-5
+
+
+def test_edge_encoder_k6_prologue_declines_what_it_does_not_serve(native):
+    rng = np.random.default_rng(5)
+    n = 100
+    pos = torch.from_numpy(rng.random((n, 2)).astype(np.float32)).to(DEV)
+    pos3 = torch.from_numpy(rng.random((n, 3)).astype(np.float32)).to(DEV)
+    mk = lambda rows: (torch.from_numpy(rng.integers(0, n, size=rows).astype(np.int32)).to(DEV),
+                       torch.from_numpy(rng.integers(0, n, size=rows).astype(np.int32)).to(DEV))
+    w = lambda o, i: torch.from_numpy(rng.standard_normal((o, i)).astype(np.float32)).to(DEV)
+    b = lambda o: torch.zeros(o, device=DEV)
+    s, d = mk(1984)  # a single small graph: the column-split kernel on a stored table is the route
+    assert native.mlp_forward_edge_features(pos, s, d, [w(64, 3), w(64, 64), w(64, 64)], [b(64)] * 3) is None
+    s, d = mk(300000)
+    assert native.mlp_forward_edge_features(pos3, s, d, [w(64, 4), w(64, 64), w(64, 64)], [b(64)] * 3) is None      # space_dim 3
+    assert native.mlp_forward_edge_features(pos, s, d, [w(128, 3), w(128, 128), w(128, 128)], [b(128)] * 3) is None  # width 128
+    assert native.mlp_forward_edge_features(pos, s, d, [w(64, 3), w(64, 64), w(64, 64)], [b(64)] * 3) is not None
+
+
 # ------------------------------------------------------------------ K4 fused MLP
 def _mlp_sd(rng, in_dim, hidden, out_dim, hidden_layers, ln):
     dims = [in_dim] + [hidden] * hidden_layers + [out_dim]

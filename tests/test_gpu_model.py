@@ -202,6 +202,28 @@ def test_fused_aggregation_forward_is_bit_identical_to_separate_k1(G, monkeypatc
     assert y2.requires_grad and torch.equal(y2.detach(), y0)
 
 
+def test_k6_folded_into_the_edge_encoder_is_bit_identical(G, monkeypatch):
+    """SURVEY 2.2 K6 "prologue of the edge-encoder K4": under no_grad the edge features are computed inside the edge encoder's
+    launch (no [E, 4] table); not a bit may change against K6 as its own launch, and with autograd on the stored form runs."""
+    from graphnet_classifier_amd import native, synthetic as S
+    batch, kw = S.make_workload("c3", scale=0.02)
+    torch.manual_seed(12)
+    m = G.GraphNet(**kw)
+    launches = []
+    real = native.edge_features
+    monkeypatch.setattr(native, "edge_features", lambda *a: (launches.append(1), real(*a))[1])
+    with torch.no_grad():
+        y1 = m(batch.x, batch.pos, batch.edge_index)
+        assert not launches, "K6 ran as its own launch although the fold serves this shape"
+        monkeypatch.setattr(native, "FOLD_EDGE_FEATURES", False)
+        y0 = m(batch.x, batch.pos, batch.edge_index)
+        assert len(launches) == 1
+    assert torch.equal(y0, y1)
+    monkeypatch.setattr(native, "FOLD_EDGE_FEATURES", True)
+    y2 = m(batch.x, batch.pos, batch.edge_index)  # training form: the backward needs the rows
+    assert len(launches) == 2 and y2.requires_grad and torch.equal(y2.detach(), y0)
+
+
 def test_edge_order_invariance(G):
     """Permuting the edge list changes only the per-destination summation order (fp32 noise)."""
     from graphnet_classifier_amd import synthetic as S
