@@ -271,7 +271,10 @@ class GraphNet(nn.Module):
         out, _ = self.graph_processor.forward_sorted(out, topo, edge_attr)                # :307
         out = self.node_decoder.forward_segments([(out, None)])                           # :308
         if topo.deferred:  # validation not read back yet: a bad edge_index must not yield a plausible result
-            out = torch.where(topo.status.any(), torch.full_like(out, float("nan")), out)
+            if out.requires_grad or not out.is_contiguous():
+                out = torch.where(topo.status.any(), torch.full_like(out, float("nan")), out)
+            else:  # inference: one launch that returns at once unless a flag is set
+                out = native.poison_if_flagged_(out, topo.status)
         return out
 
     def forward(self, x, pos, edge_index):

@@ -399,6 +399,28 @@ extern "C" int gnc_gather_rows_add_f32(const float* table, int64_t ld_table, con
   return launch_gather<true>(table, ld_table, index, addend, ld_addend, num_rows, feat_dim, out, ld_out, (hipStream_t)stream_);
 }
 
+// deferred validation (topology.py): a result computed from an edge_index with out-of-range ids must not look plausible.
+// One launch that returns at once unless a flag is set (torch.where(flags.any(), nan, out) is three launches per forward).
+__global__ __launch_bounds__(gnc::kBlock) void poison_if_flagged_kernel(float* __restrict__ out, int64_t count,
+                                                                        const int32_t* __restrict__ flags, int nflags) {
+  int any = 0;
+  for (int k = 0; k < nflags; ++k) any |= flags[k];
+  if (!any) return;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < count; t += (int64_t)gridDim.x * blockDim.x)
+    out[t] = __builtin_nanf("");
+}
+
+extern "C" int gnc_poison_if_flagged_f32(float* out, int64_t count, const int32_t* flags, int32_t nflags, void* stream_) {
+  GNC_REQUIRE(count >= 0 && nflags >= 0 && nflags <= 16, "gnc_poison_if_flagged_f32: bad sizes");
+  if (count == 0 || nflags == 0) return GNC_OK;
+  GNC_REQUIRE(out && flags, "gnc_poison_if_flagged_f32: null pointer");
+  int64_t blocks = gnc::ceil_div(count, gnc::kBlock);
+  const int64_t cap = gnc::num_cu() * 4;
+  if (blocks > cap) blocks = cap;
+  poison_if_flagged_kernel<<<dim3((unsigned)blocks), dim3(gnc::kBlock), 0, (hipStream_t)stream_>>>(out, count, flags, nflags);
+  return gnc::check_launch("poison_if_flagged_kernel");
+}
+
 extern "C" int gnc_edge_features_f32(const float* pos, int32_t space_dim, const int32_t* src, const int32_t* dst,
                                      int64_t num_edges, float* out, int64_t ld_out, void* stream_) {
   GNC_REQUIRE(num_edges >= 0 && space_dim >= 1 && space_dim <= 16 && ld_out >= space_dim + 1,

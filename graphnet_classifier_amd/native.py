@@ -61,6 +61,7 @@ _SIGNATURES = {
     "gnc_gather_rows_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p]),
     "gnc_gather_rows_add_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_int64,
                                           c_void_p]),
+    "gnc_poison_if_flagged_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int32, c_void_p]),
     "gnc_edge_features_f32": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     "gnc_sizeof_mlp_desc": (c_size_t, []),
     "gnc_mlp_supported": (c_int32, [c_void_p]),
@@ -401,6 +402,19 @@ def edge_features(pos: torch.Tensor, src: torch.Tensor, dst: torch.Tensor) -> to
         _check(lib.gnc_edge_features_f32(pos.data_ptr(), sd, src.data_ptr(), dst.data_ptr(), e, buf.data_ptr(), ld,
                                          _stream(pos)), "gnc_edge_features_f32")
     return buf[:, :sd + 1]
+
+
+def poison_if_flagged_(out: torch.Tensor, flags: torch.Tensor) -> torch.Tensor:
+    """In place: ``out`` (contiguous fp32) becomes NaN when any of the int32 device ``flags`` is set; one launch that returns
+    at once otherwise (deferred topology validation)."""
+    lib = load_library()
+    _require_cuda(out, flags)
+    if not out.is_contiguous() or out.dtype != torch.float32 or flags.dtype != torch.int32 or not flags.is_contiguous():
+        raise TypeError("poison_if_flagged_: contiguous fp32 output and contiguous int32 flags expected")
+    with torch.cuda.device(out.device):
+        _check(lib.gnc_poison_if_flagged_f32(out.data_ptr(), out.numel(), flags.data_ptr(), flags.numel(), _stream(out)),
+               "gnc_poison_if_flagged_f32")
+    return out
 
 
 # --------------------------------------------------------------------------- K4

@@ -86,8 +86,8 @@ int gnc_permute_index_checked_i64_i32(const int64_t* src, const int32_t* perm, i
  * what gnc_permute_index_checked_i64_i32 / gnc_permute_index_i64_i32 give).  Batches of small graphs whose edges are
  * contiguous in edge_index (the reference's loader yields one self-contained graph per item, utils/dataloader.py:33-53;
  * graphs of at most 2048 edges) are sorted range by range in LDS without a global radix sort;
- * any other edge list raises status[2] ON THE DEVICE and is sorted by a general stable LSD radix sort whose kernels
- * are enqueued behind it and return at once unless the flag is set - so the call never synchronises and can be
+ * any other edge list raises status[2] ON THE DEVICE and is sorted by a general stable LSD radix sort: ONE kernel that
+ * is enqueued behind it and returns at once unless the flag is set - so the call never synchronises and can be
  * captured (gated_fallback = 1).  A caller that reads the flags back anyway may pass gated_fallback = 0 (smaller
  * workspace) and run gnc_csr_build + the permutes itself when status[2] is set.
  *
@@ -95,7 +95,9 @@ int gnc_permute_index_checked_i64_i32(const int64_t* src, const int32_t* perm, i
  *                 perm are produced (src_sorted / dst_sorted ignored)
  *   status [3]    out: [0] = a destination outside [0, N), [1] = a source outside [0, N) (such ids are replaced by 0:
  *                 nothing downstream can index out of range; models/GNN.py:18-20 raises IndexError there),
- *                 [2] = the LDS path could not take this edge list (informational when gated_fallback = 1)
+ *                 [2] = 1: the LDS path could not take this edge list (informational when gated_fallback = 1: the general
+ *                 path - one gated launch whose passes meet at a grid barrier - has sorted it); 2: that barrier timed out
+ *                 (5 s; the outputs are invalid, status[0] is raised as well so that every validity check fails)
  */
 size_t gnc_topology_workspace_bytes(int64_t num_nodes, int64_t num_edges, int32_t gated_fallback);
 int gnc_topology_build(const void* src, const void* dst, int32_t index_bytes, int64_t num_edges, int64_t num_nodes,
@@ -133,6 +135,12 @@ int gnc_gather_rows_add_f32(const float* table, int64_t ld_table, const int32_t*
  */
 int gnc_edge_features_f32(const float* pos, int32_t space_dim, const int32_t* src, const int32_t* dst,
                           int64_t num_edges, float* out, int64_t ld_out, void* stream);
+
+/* ABI 19.  Deferred validation of a topology (status flags still on the device when the forward is enqueued): overwrite the
+ * `count` contiguous floats of `out` with NaN when any of flags[0 .. nflags) is non-zero; one launch that returns at once
+ * otherwise.  Keeps a forward on an edge_index with out-of-range ids (models/GNN.py:18-20 raises IndexError there) from
+ * yielding plausible numbers before the host has read the flags.  nflags <= 16. */
+int gnc_poison_if_flagged_f32(float* out, int64_t count, const int32_t* flags, int32_t nflags, void* stream);
 
 /* ---- K4: fused MLP ----------------------------------------------------------------------
  * Replaces `MLP.forward` (models/MLP.py:45-47 over the Sequential built at :24-37) together
