@@ -348,6 +348,32 @@ extern "C" int gnc_mlp_save_act_supported(const gnc_mlp_desc_t* desc) {
   return GNC_OK;
 }
 
+// ABI 19: 0 when the kernel that will serve this description reads the WEIGHT matrices where they lie, whatever their row
+// stride and alignment (nn.Linear(3, H).weight is [H, 3]): the column-split kernel and the weights-resident kernel (which
+// stages every matrix into LDS once per workgroup, with guarded scalar loads where 16-B pieces are not possible).  The
+// streaming kernels want rows of 16-B pieces: for them the caller hands over a zero-padded copy.
+extern "C" int gnc_mlp_weights_in_place_supported(const gnc_mlp_desc_t* desc) {
+  int rc = validate_desc(desc, false);
+  if (rc) return rc;
+  const int L = desc->num_linear;
+  int T = tiles_for(desc->out_dim[0]);
+  const int od = desc->out_dim[L - 1];
+  const bool narrow_out = od <= 32;
+  if (!narrow_out && tiles_for(od) > T) T = tiles_for(od);
+  bool ok = false;
+  if (desc->rows > 0) {
+    rc = launch_col16(*desc, nullptr, &ok, true);
+    if (rc) return rc;
+    if (!ok) rc = launch_resident(*desc, T, narrow_out, nullptr, &ok, true);
+    if (rc) return rc;
+  }
+  if (!ok) {
+    gnc::set_error("gnc_mlp_weights_in_place_supported: this description runs on a streaming kernel (16-B weight rows)");
+    return GNC_ERR_UNSUPPORTED;
+  }
+  return GNC_OK;
+}
+
 // K6 prologue (gnc_mlp_desc_t.ef_pos, ABI 19): served by the weights-resident kernel, and not for a small batch (there the
 // column-split kernel on a materialised [rows, 3] table is the faster route)
 extern "C" int gnc_mlp_edge_features_supported(const gnc_mlp_desc_t* desc) {

@@ -122,37 +122,66 @@ __global__ __launch_bounds__(gnc::kBlock) void scatter_sum_csr_small(
   st4(out + v * ld_out + col, a);
 }
 
-// Fix-up of the fused aggregation epilogue (mlp_resident.hip): the few destinations cut by a wave's row-range
-// boundary are summed here from the stored rows, one 16-lane group (4 floats per lane, <= 64 features) each.
+// Fix-up of the fused aggregation epilogue (mlp_resident.hip) in ONE launch: blocks [0, fix_blocks) sum the few
+// destinations cut by a wave's row-range boundary from the stored rows, one 16-lane group (4 floats per lane and 64
+// features) each; the blocks behind them give the destinations without any row their zeros (one thread per destination;
+// far cheaper than a memset of the whole [N, D] aggregate in front of the edge kernel).
+// VEC: whole 16-B pieces (feat_dim, ld_src % 4 == 0, aligned base); eight rows are requested before the first is added -
+// a destination's rows are still ADDED in ascending order starting from 0.0, as K1 does, only their loads overlap
+// (one dependent load per row made this 16 us for a dozen rows per destination).
+template <bool VEC>
 __global__ __launch_bounds__(gnc::kBlock) void agg_fixup_kernel(const float* __restrict__ src, int64_t ld_src,
                                                                 const int32_t* __restrict__ rowptr,
-                                                                const int32_t* __restrict__ fix, int32_t n_fix,
+                                                                const int32_t* __restrict__ fix, int32_t n_fix, int32_t fix_blocks,
                                                                 int32_t num_nodes, int32_t feat_dim,
                                                                 float* __restrict__ out, int64_t ld_out) {
+  if ((int)blockIdx.x >= fix_blocks) {
+    const int64_t v = (int64_t)(blockIdx.x - fix_blocks) * blockDim.x + threadIdx.x;
+    if (v >= num_nodes || rowptr[v] != rowptr[v + 1]) return;
+    for (int c = 0; c < feat_dim; ++c) out[v * ld_out + c] = 0.f;
+    return;
+  }
   const int j = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 4);
   const int col = (threadIdx.x & 15) * 4;
   if (j >= n_fix) return;
   const int32_t v = fix[j];
   if (v < 0 || v >= num_nodes) return;
+  const int32_t k0 = rowptr[v], k1 = rowptr[v + 1];
+  if (k0 == k1) return;  // no rows: the zero blocks write it
   for (int c = col; c < feat_dim; c += 64) {
     float a[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int32_t k = rowptr[v]; k < rowptr[v + 1]; ++k)
+    if constexpr (VEC) {
+      int32_t k = k0;
+      for (; k + 8 <= k1; k += 8) {
+        float4 r[8];
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        if (c + q < feat_dim) a[q] += src[(int64_t)k * ld_src + c + q];
+        for (int u = 0; u < 8; ++u) r[u] = *reinterpret_cast<const float4*>(src + (int64_t)(k + u) * ld_src + c);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          a[0] += r[u].x; a[1] += r[u].y; a[2] += r[u].z; a[3] += r[u].w;
+        }
+      }
+      float4 r[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int32_t kk = k + u < k1 ? k + u : k1 - 1;  // clamped: every load is legal, the surplus is not added
+        r[u] = *reinterpret_cast<const float4*>(src + (int64_t)kk * ld_src + c);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (k + u < k1) {
+          a[0] += r[u].x; a[1] += r[u].y; a[2] += r[u].z; a[3] += r[u].w;
+        }
+    } else {
+      for (int32_t k = k0; k < k1; ++k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (c + q < feat_dim) a[q] += src[(int64_t)k * ld_src + c + q];
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q)
       if (c + q < feat_dim) out[(int64_t)v * ld_out + c + q] = a[q];
   }
-}
-
-// ... and the destinations without any row get their zeros here (one thread per destination; far cheaper than a
-// memset of the whole [N, D] aggregate in front of the edge kernel)
-__global__ __launch_bounds__(gnc::kBlock) void agg_zero_empty_kernel(const int32_t* __restrict__ rowptr, int32_t num_nodes,
-                                                                     int32_t feat_dim, float* __restrict__ out, int64_t ld_out) {
-  const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= num_nodes || rowptr[v] != rowptr[v + 1]) return;
-  for (int c = 0; c < feat_dim; ++c) out[v * ld_out + c] = 0.f;
 }
 
 // K1, generic: any feat_dim / alignment; one wave per destination, scalar columns.
@@ -335,16 +364,16 @@ extern "C" int gnc_agg_fixup_f32(const float* src, int64_t ld_src, const int32_t
   if (feat_dim == 0 || num_nodes == 0) return GNC_OK;
   GNC_REQUIRE(rowptr && out && (n_fix == 0 || (src && fix)), "gnc_agg_fixup_f32: null pointer");
   GNC_REQUIRE(ld_src >= feat_dim && ld_out >= feat_dim, "gnc_agg_fixup_f32: leading dimension < feat_dim");
-  if (n_fix > 0) {
-    const int64_t blocks = gnc::ceil_div((int64_t)n_fix * 16, gnc::kBlock);
-    agg_fixup_kernel<<<dim3((unsigned)blocks), dim3(gnc::kBlock), 0, (hipStream_t)stream_>>>(src, ld_src, rowptr, fix, n_fix,
-                                                                                            (int32_t)num_nodes, feat_dim, out, ld_out);
-    const int rc = gnc::check_launch("agg_fixup_kernel");
-    if (rc) return rc;
-  }
-  agg_zero_empty_kernel<<<dim3((unsigned)gnc::ceil_div(num_nodes, gnc::kBlock)), dim3(gnc::kBlock), 0, (hipStream_t)stream_>>>(
-      rowptr, (int32_t)num_nodes, feat_dim, out, ld_out);
-  return gnc::check_launch("agg_zero_empty_kernel");
+  const int64_t fix_blocks = n_fix > 0 ? gnc::ceil_div((int64_t)n_fix * 16, gnc::kBlock) : 0;
+  const int64_t blocks = fix_blocks + gnc::ceil_div(num_nodes, gnc::kBlock);
+  const bool vec = feat_dim % 4 == 0 && ld_src % 4 == 0 && gnc::aligned16(src);
+  if (vec)
+    agg_fixup_kernel<true><<<dim3((unsigned)blocks), dim3(gnc::kBlock), 0, (hipStream_t)stream_>>>(
+        src, ld_src, rowptr, fix, n_fix, (int32_t)fix_blocks, (int32_t)num_nodes, feat_dim, out, ld_out);
+  else
+    agg_fixup_kernel<false><<<dim3((unsigned)blocks), dim3(gnc::kBlock), 0, (hipStream_t)stream_>>>(
+        src, ld_src, rowptr, fix, n_fix, (int32_t)fix_blocks, (int32_t)num_nodes, feat_dim, out, ld_out);
+  return gnc::check_launch("agg_fixup_kernel");
 }
 
 namespace {

@@ -253,6 +253,9 @@ int gnc_mlp_forward_f32(const gnc_mlp_desc_t* desc /* host */, void* stream);
 /* fused aggregation epilogue: 0 if this description can run with agg_out set (shape fields only) */
 int gnc_mlp_agg_supported(const gnc_mlp_desc_t* desc /* host */);
 int gnc_mlp_agg_fix_len(void); /* entries of agg_fix (2 per wave of the persistent grid) */
+/* ABI 19: 0 if the kernel that gnc_mlp_forward_f32 picks for this description reads the weight matrices where they lie
+ * whatever their row stride / alignment (the [H, 3] matrix of nn.Linear(3, H), models/GNN.py:251-256): no padded copy needed */
+int gnc_mlp_weights_in_place_supported(const gnc_mlp_desc_t* desc /* host */);
 /* ABI 19: 0 if gnc_mlp_forward_f32 serves this description with ef_pos set (pointer fields: alignment tests only) */
 int gnc_mlp_edge_features_supported(const gnc_mlp_desc_t* desc /* host */);
 /* ABI 18.  0 if the small-batch kernel (one 16-row tile per workgroup, the waves split the output features; rows up to
