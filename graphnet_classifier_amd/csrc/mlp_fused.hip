@@ -348,11 +348,12 @@ extern "C" int gnc_mlp_save_act_supported(const gnc_mlp_desc_t* desc) {
   return GNC_OK;
 }
 
-// ABI 19: 0 when the kernel that will serve this description reads the WEIGHT matrices where they lie, whatever their row
-// stride and alignment (nn.Linear(3, H).weight is [H, 3]): the column-split kernel and the weights-resident kernel (which
-// stages every matrix into LDS once per workgroup, with guarded scalar loads where 16-B pieces are not possible).  The
-// streaming kernels want rows of 16-B pieces: for them the caller hands over a zero-padded copy.
-extern "C" int gnc_mlp_weights_in_place_supported(const gnc_mlp_desc_t* desc) {
+// ABI 19: 0 when the kernel that will serve this description reads its operands where they lie: WEIGHT matrices of any row
+// stride and alignment (nn.Linear(3, H).weight is [H, 3]) - the column-split kernel and the weights-resident kernel, which
+// stages every matrix into LDS once per workgroup with guarded scalar loads where 16-B pieces are not possible - and, as the
+// only segment, a contiguous [rows, 3] table (the weights-resident kernel's 12-B row loads).  The streaming kernels want
+// rows of 16-B pieces: for them the caller hands over zero-padded copies.
+extern "C" int gnc_mlp_operands_in_place_supported(const gnc_mlp_desc_t* desc) {
   int rc = validate_desc(desc, false);
   if (rc) return rc;
   const int L = desc->num_linear;
@@ -368,7 +369,7 @@ extern "C" int gnc_mlp_weights_in_place_supported(const gnc_mlp_desc_t* desc) {
     if (rc) return rc;
   }
   if (!ok) {
-    gnc::set_error("gnc_mlp_weights_in_place_supported: this description runs on a streaming kernel (16-B weight rows)");
+    gnc::set_error("gnc_mlp_operands_in_place_supported: this description runs on a kernel that reads rows of 16-B pieces");
     return GNC_ERR_UNSUPPORTED;
   }
   return GNC_OK;

@@ -84,9 +84,11 @@ constexpr int RNT = RWAVES * 64;
 // FULL: every width of the launch is exactly 64 (segments, hidden layers, output), three Linear layers, LayerNorm, vector
 // output rows - the c3 edge processor.  The general instance keeps ~40 loop-invariant lane masks (feature / column < width)
 // and the dimensions themselves alive across the tile loop; here they are compile-time constants.
-// EF: K6 as the prologue (gnc_mlp_desc_t.ef_pos): the rows of the only segment are computed from the positions of the
+// EF = 1: K6 as the prologue (gnc_mlp_desc_t.ef_pos): the rows of the only segment are computed from the positions of the
 // edge's endpoints (two coalesced id loads one tile ahead, two 8-B gathers per row and tile) instead of being read.
-template <int HT, int OT, int NMM, int NADD, bool RESREG, bool AGG = false, bool SAVE = false, bool FULL = false, bool EF = false>
+// EF = 2: the only segment is a contiguous [rows, 3] table (the reference's node features, models/GNN.py:305): one 12-B load
+// per row and tile (lane & 31 = tile row) where it lies - no zero-padded [rows, 4] copy in front of the launch.
+template <int HT, int OT, int NMM, int NADD, bool RESREG, bool AGG = false, bool SAVE = false, bool FULL = false, int EF = 0>
 __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t d, const int num_wtiles,
                                                            const int total_chunks) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
   int ef_s = 0, ef_d = 0;
   f32x2 ef_ps = {0.f, 0.f}, ef_pd = {0.f, 0.f};
   const __amdgpu_buffer_rsrc_t ef_win =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(EF ? d.ef_pos : nullptr), 0, EF ? (int)(uint32_t)(d.ef_nodes * 8) : 0, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(EF == 1 ? d.ef_pos : nullptr), 0, EF == 1 ? (int)(uint32_t)(d.ef_nodes * 8) : 0, 0x00020000);
   auto ef_ids = [&](int t) {
     const int tc = t < last_wt ? t : last_wt;
     int r = tc * RPW + (lane & 31);
@@ -220,17 +222,36 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
     *reinterpret_cast<f32x4*>(abuf + i * LDSW + 4 * h) = v;
     compiler_lds_barrier();
   };
+  // EF = 2: the next tile's [*, 3] rows
+  typedef float f32x3 __attribute__((ext_vector_type(3)));
+  f32x3 n3_row = {0.f, 0.f, 0.f};
+  const __amdgpu_buffer_rsrc_t n3_win = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(EF == 2 ? d.seg[0].ptr : nullptr), 0, EF == 2 ? (int)(uint32_t)(d.rows * 12) : 0, 0x00020000);
+  auto n3_fetch = [&](int t) {  // launcher: rows * 12 < 4 GiB; rows past the end read as zeros
+    typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+    const int tc = t < last_wt ? t : last_wt;
+    n3_row = __builtin_bit_cast(f32x3, (u32x3)__builtin_amdgcn_raw_buffer_load_b96(n3_win, (uint32_t)(tc * RPW + (lane & 31)) * 12u, 0, 0));
+  };
+  auto n3_stage = [&]() {
+    compiler_lds_barrier();
+    f32x4 v = {n3_row.x, n3_row.y, n3_row.z, 0.f};
+    if (h) v = f32x4{0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4*>(abuf + i * LDSW + 4 * h) = v;
+    compiler_lds_barrier();
+  };
   uint32_t off0 = 0;
-  if constexpr (EF) {
+  if constexpr (EF == 1) {
     ef_ids(wt);
     ef_fetch();
     ef_ids(wt + stride);
+  } else if constexpr (EF == 2) {
+    n3_fetch(wt);
   } else {
     load_rows(cur, sv[0], wt, row_offset(wt, sv[0]));
   }
 #pragma unroll
   for (int s = 1; s < NS; ++s) offs[s] = row_offset(wt, sv[s]);
-  if constexpr (!EF) off0 = row_offset(wt + stride, sv[0]);
+  if constexpr (EF == 0) off0 = row_offset(wt + stride, sv[0]);
 
   const int col_out = c4 * 4;
   const bool vec_out = FULL || ((out_dim % 4 == 0) && (d.ld_out % 4 == 0) && ((reinterpret_cast<uintptr_t>(d.out) & 15u) == 0));
@@ -263,7 +284,8 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
 #pragma unroll
     for (int s = 0; s < NMM; ++s) {
       bool interleaved = false;
-      if constexpr (EF) ef_stage();
+      if constexpr (EF == 1) ef_stage();
+      else if constexpr (EF == 2) n3_stage();
       else stage(cur, sv[s].width);
       PROBE(0);  // wait for the step's rows + staging
       // request what comes next before the MFMAs of this step start
@@ -313,9 +335,11 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
             offs[NMM] = row_offset(nwt, sv[NMM]);
             offs[NMM + 1] = row_offset(nwt, sv[NMM + 1]);
           }
-        } else if constexpr (EF) {
+        } else if constexpr (EF == 1) {
           ef_fetch();  // the next tile's endpoints (ids fetched one tile ago), then the ids of the tile after it
           ef_ids(nwt + stride);
+        } else if constexpr (EF == 2) {
+          n3_fetch(nwt);
         } else {
           load_rows(cur, sv[0], nwt, off0);
           off0 = row_offset(nwt + stride, sv[0]);
@@ -440,8 +464,10 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
     // The compiler's counted vmcnt waits do not know about the asm stores below; make it collect the
     // next tile's prefetched rows (issued >= one Linear ago) BEFORE the stores join the queue, so that
     // no later wait for them has to sit out the stores as well.
-    if constexpr (EF) {
+    if constexpr (EF == 1) {
       asm volatile("" ::"v"(ef_ps), "v"(ef_pd), "v"(ef_s), "v"(ef_d));
+    } else if constexpr (EF == 2) {
+      asm volatile("" ::"v"(n3_row.x), "v"(n3_row.y), "v"(n3_row.z));
     } else {
 #pragma unroll
       for (int p = 0; p < NP; ++p) asm volatile("" ::"v"(cur[p]));
@@ -498,7 +524,7 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
   PROBE_END();
 }
 
-template <int HT, int OT, int NMM, int NADD, bool RESREG, bool AGG = false, bool SAVE = false, bool FULL = false, bool EF = false>
+template <int HT, int OT, int NMM, int NADD, bool RESREG, bool AGG = false, bool SAVE = false, bool FULL = false, int EF = 0>
 int launch(const gnc_mlp_desc_t& d, int total_chunks, size_t smem, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
@@ -535,9 +561,18 @@ int gnc_mlp::launch_resident(const gnc_mlp_desc_t& d, int T, bool narrow_out, hi
   if (L > 1 && d.activation != GNC_ACT_RELU) return GNC_OK;
   // shape of the step schedule: MATMUL segments first, then exactly 0 or 2 ADD segments
   int nmm = 0, nadd = 0;
+  bool n3 = false;
   for (int s = 0; s < d.num_segments; ++s) {
     const gnc_mlp_segment_t& g = d.seg[s];
     if (d.ef_pos && s == 0) continue;  // computed rows: nothing is read through this segment's table
+    // a contiguous [rows, 3] table as the only input (the node features, models/GNN.py:305): read where it lies (EF = 2)
+    if (s == 0 && d.num_segments == 1 && !g.index && g.mode == GNC_SEG_MATMUL && g.width == 3 && g.ld == 3 &&
+        (reinterpret_cast<uintptr_t>(g.ptr) & 3u) == 0 && d.rows * 12 <= 0xffffffffll && !d.residual && !d.save_act[0] && !d.agg_out &&
+        !narrow_out && L >= 2 && T == 2) {
+      n3 = true;
+      ++nmm;
+      continue;
+    }
     if (g.width > KC || g.ld % 4 != 0 || !al16(g.ptr)) return GNC_OK;
     // gathers go through a buffer window over the whole table: its size must be stated and below 4 GiB
     if (g.index && (g.table_rows <= 0 || g.table_rows * (int64_t)g.ld * 4 > 0xffffffffll)) return GNC_OK;
@@ -581,7 +616,12 @@ int gnc_mlp::launch_resident(const gnc_mlp_desc_t& d, int T, bool narrow_out, hi
   if (d.ef_pos) {
     *launched = true;
     if (probe_only) return GNC_OK;
-    return launch<2, 2, 1, 0, false, false, false, false, true>(d, total_chunks, smem, stream);
+    return launch<2, 2, 1, 0, false, false, false, false, 1>(d, total_chunks, smem, stream);
+  }
+  if (n3) {
+    *launched = true;
+    if (probe_only) return GNC_OK;
+    return launch<2, 2, 1, 0, false, false, false, false, 2>(d, total_chunks, smem, stream);
   }
   if (d.save_act[0]) {
     // training forward: SAVE instances exist for the shapes whose K8 kernel reads the saved tensors (the fused data +

@@ -31,7 +31,7 @@ _SIGNATURES = {
     "gnc_target_arch": (c_char_p, []),
     "gnc_mlp_agg_supported": (c_int32, [c_void_p]),
     "gnc_mlp_edge_features_supported": (c_int32, [c_void_p]),
-    "gnc_mlp_weights_in_place_supported": (c_int32, [c_void_p]),
+    "gnc_mlp_operands_in_place_supported": (c_int32, [c_void_p]),
     "gnc_mlp_save_act_supported": (c_int32, [c_void_p]),
     "gnc_mlp_agg_fix_len": (c_int32, []),
     "gnc_mlp_small_batch_supported": (c_int32, [c_void_p]),
@@ -490,12 +490,12 @@ def _rows_of(segments, rows) -> int:
     return int(i0.numel() if i0 is not None else t0.size(0))
 
 
-def _prepare_mlp(segments, weights, biases, residual, rows, modes, vector_rows: bool = True, pad_weights: bool = True):
+def _prepare_mlp(segments, weights, biases, residual, rows, modes, vector_rows: bool = True):
     """Shared argument preparation of the forward and backward launches (see mlp_forward).  ``vector_rows=False`` hands
-    tables and weights over as they are (row-major, any alignment): only for a launch the small-batch kernel takes;
-    ``pad_weights=False`` does so for the weights alone (gnc_mlp_weights_in_place_supported)."""
+    tables and weights over as they are (row-major, any alignment): only for a launch whose kernel reads them in place
+    (gnc_mlp_small_batch_supported, gnc_mlp_operands_in_place_supported)."""
     _vr = _vector_rows if vector_rows else (lambda t: t)
-    _vw = _vr if pad_weights else (lambda t: t)
+    _vw = _vr
     modes = list(modes) if modes is not None else [SEG_MATMUL] * len(segments)
     segs, wcol = [], 0
     for (table, index), mode in zip(segments, modes):
@@ -562,16 +562,17 @@ def mlp_forward(segments, weights, biases, ln=None, activation: str = "ReLU", ac
     lib = load_library()
     given = (segments, weights, biases, residual, rows, modes)
     small = _rows_of(segments, rows) <= _small_batch_rows(lib)
-    # inference launches without extras: the weights go over as they lie first (an [H, 3] first-layer matrix costs a pad
-    # launch pair per call otherwise) and are padded only when a streaming kernel will serve the launch
-    raw_w = not small and save_act is None and aggregate is None
-    segs, weights, biases, residual, rows, modes = _prepare_mlp(*given, vector_rows=not small, pad_weights=not raw_w)
+    # inference launches without extras: tables and weights go over as they lie first ([N, 3] inputs and [H, 3] first-layer
+    # matrices cost a pad launch pair each per call otherwise) and are padded only when the kernel that will serve the launch
+    # reads rows of 16-B pieces
+    raw = not small and save_act is None and aggregate is None
+    segs, weights, biases, residual, rows, modes = _prepare_mlp(*given, vector_rows=not (small or raw))
     dev = segs[0][0].device
     out = torch.empty(rows, weights[-1].size(0), dtype=torch.float32, device=dev)
     desc = make_mlp_desc(segs, weights, biases, ln, activation, act_param, residual, out, rows)
-    if raw_w and any(w.data_ptr() % 16 or _ld(w) % 4 for w in weights) and \
-            lib.gnc_mlp_weights_in_place_supported(ctypes.byref(desc)) != 0:
-        weights = [_vector_rows(w) for w in weights]
+    if raw and any(t.data_ptr() % 16 or _ld(t) % 4 for t in [sg[0] for sg in segs] + weights) and \
+            lib.gnc_mlp_operands_in_place_supported(ctypes.byref(desc)) != 0:
+        segs, weights, biases, residual, rows, modes = _prepare_mlp(*given)  # a streaming kernel: rows of 16-B pieces
         desc = make_mlp_desc(segs, weights, biases, ln, activation, act_param, residual, out, rows)
     if small and lib.gnc_mlp_small_batch_supported(ctypes.byref(desc)) != 0:
         # every other kernel reads rows as 16-B pieces: 3-column inputs / [H, 3] weights go through a zero-padded copy

@@ -253,9 +253,11 @@ int gnc_mlp_forward_f32(const gnc_mlp_desc_t* desc /* host */, void* stream);
 /* fused aggregation epilogue: 0 if this description can run with agg_out set (shape fields only) */
 int gnc_mlp_agg_supported(const gnc_mlp_desc_t* desc /* host */);
 int gnc_mlp_agg_fix_len(void); /* entries of agg_fix (2 per wave of the persistent grid) */
-/* ABI 19: 0 if the kernel that gnc_mlp_forward_f32 picks for this description reads the weight matrices where they lie
- * whatever their row stride / alignment (the [H, 3] matrix of nn.Linear(3, H), models/GNN.py:251-256): no padded copy needed */
-int gnc_mlp_weights_in_place_supported(const gnc_mlp_desc_t* desc /* host */);
+/* ABI 19: 0 if the kernel that gnc_mlp_forward_f32 picks for this description reads its operands where they lie: weight
+ * matrices of any row stride / alignment (the [H, 3] matrix of nn.Linear(3, H), models/GNN.py:251-256) and a contiguous
+ * [rows, 3] table as the only segment (the node features of models/GNN.py:305) - no zero-padded copies needed.  Every other
+ * kernel reads rows of 16-B pieces (tables and weights 16-B aligned, leading dimensions % 4 == 0). */
+int gnc_mlp_operands_in_place_supported(const gnc_mlp_desc_t* desc /* host */);
 /* ABI 19: 0 if gnc_mlp_forward_f32 serves this description with ef_pos set (pointer fields: alignment tests only) */
 int gnc_mlp_edge_features_supported(const gnc_mlp_desc_t* desc /* host */);
 /* ABI 18.  0 if the small-batch kernel (one 16-row tile per workgroup, the waves split the output features; rows up to

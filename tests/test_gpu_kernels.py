@@ -301,6 +301,31 @@ def test_edge_encoder_with_k6_as_its_prologue_is_bit_identical(native, hidden, o
     assert max_abs(got.cpu(), O.mlp_forward(sd, "m", O.edge_features(pos.cpu(), ei))) <= 1e-5
 
 
+@pytest.mark.parametrize("rows", [70001, 33 * 1024, 40000])
+def test_three_column_input_and_weights_are_read_where_they_lie(native, rows):
+    """ABI 19 (gnc_mlp_operands_in_place_supported): the node encoder's [N, 3] input and [H, 3] first-layer matrix
+    (models/GNN.py:251-253, :305) go to the weights-resident kernel unpadded; bit-identical to the launch on zero-padded copies."""
+    rng = np.random.default_rng(rows)
+    x = torch.from_numpy(rng.standard_normal((rows, 3)).astype(np.float32)).to(DEV)
+    sd = _mlp_sd(rng, 3, 64, 64, 2, True)
+    ws = [sd[f"m.model.{i}.weight"].to(DEV) for i in (0, 2, 4)]
+    bs = [sd[f"m.model.{i}.bias"].to(DEV) for i in (0, 2, 4)]
+    lnp = (sd["m.model.5.weight"].to(DEV), sd["m.model.5.bias"].to(DEV), 1e-5)
+    pad_launches = []
+    real = native._vector_rows
+    native._vector_rows = lambda t: (pad_launches.append(tuple(t.shape)), real(t))[1]
+    try:
+        got = native.mlp_forward([(x, None)], ws, bs, ln=lnp)
+    finally:
+        native._vector_rows = real
+    assert not pad_launches, f"padded copies were made: {pad_launches}"
+    xp = torch.nn.functional.pad(x, (0, 1))[:, :3]
+    w0p = torch.nn.functional.pad(ws[0], (0, 1))[:, :3]
+    ref = native.mlp_forward([(xp, None)], [w0p] + ws[1:], bs, ln=lnp)
+    assert torch.equal(got, ref)
+    assert max_abs(got.cpu(), O.mlp_forward(sd, "m", x.cpu())) <= 1e-5
+
+
 def test_edge_encoder_k6_prologue_declines_what_it_does_not_serve(native):
     rng = np.random.default_rng(5)
     n = 100
