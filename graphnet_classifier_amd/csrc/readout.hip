@@ -13,6 +13,10 @@
 
 namespace {
 
+// nn.ReLU keeps a NaN (fmaxf would swallow it: a poisoned forward must not turn into plausible logits)
+__device__ __forceinline__ float relu_keep_nan(float v) { return v < 0.f ? 0.f : v; }
+
+
 constexpr int RT = 256;       // threads per workgroup
 constexpr int RMAXH = 1024;   // fc1 / fc2 widths the LDS arrays are sized for
 constexpr int RMAXC = 64;     // classes
@@ -48,7 +52,7 @@ __global__ __launch_bounds__(RT) void readout_fwd_kernel(const float* __restrict
   }
   const float s = block_sum(acc, red, tid);
   if (tid == 0) {
-    h1[r] = fmaxf(s + (b1 ? b1[r] : 0.f), 0.f);
+    h1[r] = relu_keep_nan(s + (b1 ? b1[r] : 0.f));
     __threadfence();
     last = atomicAdd(ticket, 1u) == (unsigned)(gridDim.x - 1) ? 1 : 0;
   }
@@ -64,7 +68,7 @@ __global__ __launch_bounds__(RT) void readout_fwd_kernel(const float* __restrict
 #pragma unroll
     for (int sft = 32; sft > 0; sft >>= 1) a += __shfl_down(a, sft, 64);
     if ((tid & 63) == 0) {
-      const float v = fmaxf(a + (b2 ? b2[o] : 0.f), 0.f);
+      const float v = relu_keep_nan(a + (b2 ? b2[o] : 0.f));
       sh2[o] = v;
       h2[o] = v;
     }

@@ -39,11 +39,16 @@ __device__ __forceinline__ int checked_id(IdxT v, int64_t n, bool* bad) {
   return ok ? (int)v : 0;  // memory-safe stand-in; the flag makes the host raise (or the forward poison its output)
 }
 
-// ---- pass A: per-tile min / max of the (validated) destinations
+// ---- pass A: per-tile min / max of the (sanitised) destinations.  Also clears the three status words for the kernels behind it
+// (pass C re-reads and validates every destination, so nothing is flagged here).  NOT a hipMemsetAsync: inside a captured
+// hipGraph the runtime's memset node was seen to write a foreign byte pattern (0x04...) into the flags on replays that followed
+// an unrelated reduction launched outside the graph (round 3, any-topology training step) - the flags of a capturable build are
+// written by this library's own kernels only.
 template <typename IdxT>
 __global__ __launch_bounds__(NT) void topo_tile_minmax(const IdxT* __restrict__ dst, int64_t E, int64_t N, int* __restrict__ tmin,
                                                        int* __restrict__ tmax, int* __restrict__ status) {
   __shared__ int smin[NT / 64], smax[NT / 64];
+  if (blockIdx.x == 0 && threadIdx.x < 3) status[threadIdx.x] = 0;
   const int64_t base = (int64_t)blockIdx.x * TT;
   int mn = IMAX, mx = -1;
   bool bad = false;
@@ -56,7 +61,7 @@ __global__ __launch_bounds__(NT) void topo_tile_minmax(const IdxT* __restrict__ 
       mx = v > mx ? v : mx;
     }
   }
-  if (bad) status[0] = 1;  // every writer stores the same value
+  (void)bad;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const int a = __shfl_xor(mn, o, 64), b = __shfl_xor(mx, o, 64);
@@ -76,6 +81,12 @@ __global__ __launch_bounds__(NT) void topo_tile_minmax(const IdxT* __restrict__ 
     tmin[blockIdx.x] = mn;
     tmax[blockIdx.x] = mx;
   }
+}
+
+// an empty edge list: row pointers and flags cleared by a kernel (see pass A for why not a memset)
+__global__ void topo_clear(int* __restrict__ rowptr, int64_t count, int* __restrict__ status) {
+  if (blockIdx.x == 0 && threadIdx.x < 3) status[threadIdx.x] = 0;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < count; k += (int64_t)gridDim.x * blockDim.x) rowptr[k] = 0;
 }
 
 // ---- pass B (one workgroup): P[t] = max over tiles before t (-1), S[t] = min over tiles after t (IMAX)
@@ -565,9 +576,13 @@ Workspace carve(void* base_, int64_t E, bool fallback) {
 template <typename IdxT, bool WITH_ENDPOINTS>
 int build(const IdxT* src, const IdxT* dst, int64_t E, int64_t N, int* rowptr, int* perm, int* src_sorted, int* dst_sorted, int* status,
           void* workspace, size_t workspace_bytes, int gated_fallback, hipStream_t stream) {
-  int rc = gnc::check_hip(hipMemsetAsync(status, 0, 3 * sizeof(int32_t), stream), "hipMemsetAsync(status)");
-  if (rc) return rc;
-  if (E == 0) return gnc::check_hip(hipMemsetAsync(rowptr, 0, (size_t)(N + 1) * sizeof(int32_t), stream), "hipMemsetAsync(rowptr)");
+  int rc = GNC_OK;
+  if (E == 0) {
+    int64_t cb = gnc::ceil_div(N + 1, 256);
+    cb = cb < 1024 ? cb : 1024;
+    topo_clear<<<(unsigned)cb, 256, 0, stream>>>(rowptr, N + 1, status);
+    return gnc::check_launch("topo_clear");
+  }
   const Workspace w = carve(workspace, E, gated_fallback != 0);
   if (workspace_bytes < w.bytes) {
     gnc::set_error("gnc_topology_build: workspace too small (%zu < %zu)", workspace_bytes, w.bytes);

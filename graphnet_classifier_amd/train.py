@@ -161,23 +161,56 @@ class CapturedTrainStep:
     issues the ONE all-reduce and the fused Adam launch directly after the replay."""
 
     def __init__(self, model: nn.Module, optimizer: FusedAdam, criterion, sample, label, loss_sum: torch.Tensor, *,
-                 forward=None, loss_scale: float = 1.0, capture_error_mode: str = "global"):
+                 forward=None, loss_scale: float = 1.0, capture_error_mode: str = "global", edge_capacity: int | None = None):
         x, pos, edge_index = sample
         dev = require_gpu_param(next(model.parameters()), "CapturedTrainStep")
         fp = optimizer.fp
         self.optimizer = optimizer
         self.edge_index_host = edge_index
-        self.x = x.to(device=dev, dtype=torch.float32).clone()
-        self.pos = pos.to(device=dev, dtype=torch.float32).clone()
-        self.edge_index = edge_index.to(dev)
+        self.edge_capacity = edge_capacity
+        self.num_nodes = int(x.size(0))
         self.label = torch.as_tensor(label).to(dev).clone()
         self.loss_sum = loss_sum
         self.collective_outside = _world(fp.reducer.group) > 1
-        from .topology import get_topology
-        # the build's host sync happens here, outside the capture; the reference keeps the CSR arrays alive for the graph
-        self.topo = get_topology(self.edge_index, self.x.size(0), dev)
+        from .topology import GraphTopology, get_topology
+        if edge_capacity is None:
+            self.x = x.to(device=dev, dtype=torch.float32).clone()
+            self.pos = pos.to(device=dev, dtype=torch.float32).clone()
+            self.edge_index = edge_index.to(dev)
+            # the build's host sync happens here, outside the capture; the reference keeps the CSR arrays alive for the graph
+            self.topo = get_topology(self.edge_index, self.x.size(0), dev)
+            fwd = forward if forward is not None else (lambda mod, xx, pp, ee: mod((xx, pp, ee)))
+        else:
+            # ANY topology over the same node count (the reference's superpixel graphs: a new region adjacency per image,
+            # utils/image_to_graph/image_to_graph_superpixel.py:31-66, one graph per optimizer step, main.py:60): the captured
+            # buffers hold extra DUMMY nodes with zero features and ``edge_capacity`` edges, the unused tail of which are
+            # self-loops of the dummies (spread round-robin, at most 8 each: ONE dummy would be a hub of hundreds of rows
+            # that the per-destination kernels - K1, the topology build's in-destination ranking - walk serially: 0.95 ms
+            # per step against 0.6).  Those rows only ever talk to dummies, whose outputs the read-out never sees, so
+            # they contribute exact zeros to the logits and to every gradient; the topology build (device flags, no host
+            # sync) is PART of the captured step, so a replay sorts whatever edge list the buffer holds.
+            n, e = self.num_nodes, int(edge_index.size(1))
+            if e > edge_capacity:
+                raise ValueError(f"CapturedTrainStep: {e} edges exceed edge_capacity {edge_capacity}")
+            if forward is None and not (hasattr(model, "graph_net") and hasattr(model, "classifier")):
+                raise TypeError("CapturedTrainStep(edge_capacity=...): pass forward= for a module that is not a CombinedModel")
+            dummies = max(1, (edge_capacity + 7) // 8)
+            self.x = torch.zeros(n + dummies, *x.shape[1:], dtype=torch.float32, device=dev)
+            self.pos = torch.zeros(n + dummies, *pos.shape[1:], dtype=torch.float32, device=dev)
+            self._tail = n + torch.arange(edge_capacity, dtype=torch.int64, device=dev) % dummies  # slot k's dummy self-loop
+            self.edge_index = self._tail.repeat(2, 1)
+            self.x[:n].copy_(x)
+            self.pos[:n].copy_(pos)
+            self.edge_index[:, :e].copy_(edge_index)
+            self.topo, self._status = None, None
+            self._range_flag = torch.zeros((), dtype=torch.bool, device=dev)
 
-        fwd = forward if forward is not None else (lambda mod, xx, pp, ee: mod((xx, pp, ee)))
+            def padded_forward(mod, xx, pp, ee):
+                topo = GraphTopology(ee, xx.size(0), device=dev, validate="deferred")  # never the cache: built in every step
+                self._status = topo.status  # the capture's own flags: every replay rewrites them
+                y = mod.graph_net.forward_device(xx, pp, topo)
+                return mod.classifier(y[:n].flatten())
+            fwd = forward if forward is not None else padded_forward
         through = _Through(model, fwd)
         # private leaves over the parameters' storage (the flat buffer): see the class docstring
         wanted = dict(zip(fp.names, range(len(fp.names))))
@@ -236,6 +269,9 @@ class CapturedTrainStep:
 
     def matches(self, sample) -> bool:
         x, pos, edge_index = sample
+        if self.edge_capacity is not None:
+            return (x.size(0) == self.num_nodes and x.shape[1:] == self.x.shape[1:] and pos.shape[1:] == self.pos.shape[1:]
+                    and edge_index.dim() == 2 and edge_index.size(1) <= self.edge_capacity)
         return x.shape == self.x.shape and pos.shape == self.pos.shape and _same_topology(edge_index, self.edge_index_host)
 
     def replay(self) -> None:
@@ -245,11 +281,35 @@ class CapturedTrainStep:
             self._finish()
 
     def __call__(self, sample, label) -> None:
-        x, pos, _ = sample
-        self.x.copy_(x, non_blocking=True)
-        self.pos.copy_(pos, non_blocking=True)
+        x, pos, edge_index = sample
+        if self.edge_capacity is None:
+            self.x.copy_(x, non_blocking=True)
+            self.pos.copy_(pos, non_blocking=True)
+        else:
+            n, e = self.num_nodes, int(edge_index.size(1))
+            if x.size(0) != n or e > self.edge_capacity:
+                raise ValueError(f"CapturedTrainStep: sample with {x.size(0)} nodes / {e} edges does not fit the captured "
+                                 f"{n} nodes / {self.edge_capacity} edges")
+            # ids in [n, n + dummies) would pass the topology build's range check but are not nodes of THIS graph
+            if e and not edge_index.is_cuda:
+                if int(edge_index.max()) >= n or int(edge_index.min()) < 0:  # host tensor (the loader's): checked here, at once
+                    raise IndexError(f"edge_index has node ids outside [0, {n})")
+            elif e:
+                self._range_flag |= (edge_index >= n).any()  # device tensor: no sync, read by check()
+            self.x[:n].copy_(x, non_blocking=True)
+            self.pos[:n].copy_(pos, non_blocking=True)
+            self.edge_index[:, :e].copy_(edge_index, non_blocking=True)
+            self.edge_index[:, e:].copy_(self._tail[e:])  # the tail: self-loops of the dummy nodes
         self.label.copy_(torch.as_tensor(label), non_blocking=True)
         self.replay()
+
+    def check(self) -> None:
+        """Padded form: read the device flags of the LAST replayed topology build (one host sync) and raise the IndexError the
+        reference's scatter raises for node ids outside the graph (models/GNN.py:18-20)."""
+        status = getattr(self, "_status", None)
+        if status is not None and bool((status.any() | self._range_flag).item()):
+            self._range_flag.zero_()
+            raise IndexError(f"edge_index has node ids outside [0, {self.num_nodes})")
 
 
 # --------------------------------------------------------------------------- the run's side effects
@@ -336,17 +396,39 @@ class _SampleStepper:
         self.model, self.optimizer, self.criterion, self.loss_sum, self.device = model, optimizer, criterion, loss_sum, device
         self.capture = capture
         self.captured: CapturedTrainStep | None = None
+        self.padded: CapturedTrainStep | None = None
+        self._padded_captures = 0
         self._previous = None
 
+    MAX_PADDED_CAPTURES = 4  # a dataset whose edge counts keep outgrowing the capacity goes back to eager steps
+
     def _try_replay(self, sample, label) -> bool:
-        if self.captured is None and self._previous is not None and self._previous[0].shape == sample[0].shape \
-                and _same_topology(self._previous[2], sample[2]):
+        prev = self._previous
+        same_nodes = prev is not None and prev[0].shape == sample[0].shape and prev[1].shape == sample[1].shape
+        if self.captured is None and same_nodes and _same_topology(prev[2], sample[2]):
             self.captured = CapturedTrainStep(self.model, self.optimizer, self.criterion, sample, label, self.loss_sum)
         if self.captured is not None and self.captured.matches(sample):
             self.captured(sample, label)
             return True
+        # a NEW topology over the same node count (superpixel graphs): the padded form, topology build inside the graph
+        if self.padded is not None and not self.padded.matches(sample) and sample[0].size(0) == self.padded.num_nodes:
+            self.padded = None  # more edges than the capacity: capture again with room to spare
+        if (self.padded is None and same_nodes and self._padded_captures < self.MAX_PADDED_CAPTURES
+                and hasattr(self.model, "graph_net") and hasattr(self.model, "classifier")):
+            most = max(int(prev[2].size(1)), int(sample[2].size(1)))
+            capacity = (most * 3 // 2 + 255) // 256 * 256
+            self.padded = CapturedTrainStep(self.model, self.optimizer, self.criterion, sample, label, self.loss_sum,
+                                            edge_capacity=capacity)
+            self._padded_captures += 1
+        if self.padded is not None and self.padded.matches(sample):
+            self.padded(sample, label)
+            return True
         self._previous = sample
         return False
+
+    def check(self) -> None:
+        if self.padded is not None:
+            self.padded.check()
 
     def __call__(self, sample, label) -> None:
         dev = self.device
@@ -398,6 +480,7 @@ def train(model, dataset, epochs, patience=5, output_path='weights', start_weigh
                     stepper(sample, label)
                     steps += 1
                 avg_loss = float(loss_sum.item()) / max(1, steps)                      # :47 (the epoch's one host sync)
+                stepper.check()  # replayed topology builds: node ids outside the graph raise here (models/GNN.py:18-20)
                 history.append(avg_loss)
                 journal.epoch(epoch, avg_loss, time.time() - started)
                 if stopper.observe(avg_loss):                                          # :57-66
@@ -410,5 +493,5 @@ def train(model, dataset, epochs, patience=5, output_path='weights', start_weigh
             journal.close(stopper.best, final_path)
     finally:
         torch.cuda.current_stream(dev).wait_stream(run_stream)
-    return {"avg_loss": history, "best_loss": stopper.best, "log_path": journal.path, "captured": stepper.captured is not None,
+    return {"avg_loss": history, "best_loss": stopper.best, "log_path": journal.path, "captured": stepper.captured is not None, "captured_any_topology": stepper.padded is not None,
             "optimizer": optimizer}

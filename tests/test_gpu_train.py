@@ -317,3 +317,88 @@ def test_captured_step_restores_batchnorm_buffers(G):
     step(s0, l0)
     torch.cuda.synchronize()
     assert any(not torch.equal(v, before[k]) for k, v in m.state_dict().items() if "running_mean" in k)
+
+
+def _random_graph_dataset(n, count, seed, lo=150, hi=260):
+    """Graphs over the same ``n`` nodes whose edge lists differ in content AND length (what a region-adjacency graph of a
+    new image is: utils/image_to_graph/image_to_graph_superpixel.py:31-66)."""
+    rng = np.random.default_rng(seed)
+    ds = []
+    for _ in range(count):
+        e = int(rng.integers(lo, hi))
+        ei = torch.from_numpy(rng.integers(0, n, size=(2, e)).astype(np.int64))
+        x = torch.from_numpy(rng.random((n, 3), dtype=np.float32))
+        pos = torch.from_numpy((rng.random((n, 2)) * 8).astype(np.float32))
+        ds.append(((x, pos, ei), torch.tensor(int(rng.integers(0, 2)))))
+    return ds
+
+
+def test_any_topology_captured_training_matches_eager_training(G, tmp_path):
+    """One graph per optimizer step with a NEW topology every step (main.py:60 on superpixel graphs): train() replays ONE
+    captured step whose buffers hold a dummy node and spare edge slots and whose topology build is part of the graph.
+    The padding contributes exact zeros: same per-epoch losses and final weights as the eager loop."""
+    from graphnet_classifier_amd.train import train
+    g = load_golden("g8_training_run.npz")
+    ds = _random_graph_dataset(64, 10, seed=7)
+    out = {}
+    for capture in (False, True):
+        m = G.CombinedModel(G.GraphNet(**_kwargs(g)), num_nodes=64, classes=2)
+        m.load_state_dict(sub_state_dict(g, "before/"), strict=True)
+        r = train(m, ds, 3, patience=5, output_path=str(tmp_path / str(capture)), capture=capture)
+        assert r["captured_any_topology"] is capture  # (a topology that comes back also gets its own fixed capture)
+        out[capture] = ({k: v.detach().cpu().clone() for k, v in m.state_dict().items()}, r["avg_loss"])
+    for a, b in zip(out[True][1], out[False][1]):
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), (out[True][1], out[False][1])
+    close = total = 0
+    for k in out[True][0]:
+        d = (out[True][0][k] - out[False][0][k]).abs()
+        close += int((d <= 2e-5).sum())
+        total += d.numel()
+    # an entry whose gradient is at rounding level moves by ~lr per step in a direction fp32 noise decides (as in G8)
+    assert close >= 0.97 * total, (close, total)
+
+
+def test_any_topology_captured_step_limits_and_flags(G):
+    from graphnet_classifier_amd.train import CapturedTrainStep, FlatParameters, FusedAdam
+    g = load_golden("g8_training_run.npz")
+    m = G.CombinedModel(G.GraphNet(**_kwargs(g)), num_nodes=64, classes=2)
+    m.load_state_dict(sub_state_dict(g, "before/"), strict=True)
+    opt = FusedAdam(FlatParameters(m), lr=1e-3)
+    loss_sum = torch.zeros((), dtype=torch.float64, device=DEV)
+    ds = _random_graph_dataset(64, 3, seed=9)
+    with pytest.raises(ValueError):
+        CapturedTrainStep(m, opt, torch.nn.CrossEntropyLoss(), ds[0][0], ds[0][1], loss_sum, edge_capacity=16)
+    step = CapturedTrainStep(m, opt, torch.nn.CrossEntropyLoss(), ds[0][0], ds[0][1], loss_sum, edge_capacity=512)
+    before = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    assert float(loss_sum.item()) == 0.0  # capturing does not train
+    for (sample, label) in ds:
+        assert step.matches(sample)
+        step(sample, label)
+    step.check()
+    assert np.isfinite(float(loss_sum.item())) and float(loss_sum.item()) > 0
+    assert any(not torch.equal(before[k], v) for k, v in m.state_dict().items())
+    # the eager step on the same sample gives the same loss
+    x, pos, ei = ds[0][0]
+    big = torch.cat([ei, torch.randint(0, 64, (2, 600))], dim=1)
+    assert not step.matches((x, pos, big))
+    with pytest.raises(ValueError):
+        step((x, pos, big), ds[0][1])
+    # device tensors in: the range test is a reduction launched OUTSIDE the graph right in front of the replay (regression: the
+    # flags used to be cleared by a hipMemsetAsync node, which such a launch made write a foreign byte pattern on the next replay)
+    for (sample, label) in ds:
+        step(tuple(v.to(DEV) for v in sample), label)
+        step.check()
+    assert np.isfinite(float(loss_sum.item()))
+    bad = ei.clone()
+    bad[1, 5] = 64 + 7  # a dummy node's id: not a node of this graph
+    with pytest.raises(IndexError):  # host tensor: raised at once, as models/GNN.py:18-20 does
+        step((x, pos, bad), ds[0][1])
+    step((x.to(DEV), pos.to(DEV), bad.to(DEV)), ds[0][1])  # device tensor: no sync in the step, the flag waits for check()
+    with pytest.raises(IndexError):
+        step.check()
+    step.check()  # reported once
+    bad[1, 5] = 100000  # beyond the dummies too: the topology build's own flag, and a poisoned forward
+    step((x.to(DEV), pos.to(DEV), bad.to(DEV)), ds[0][1])
+    with pytest.raises(IndexError):
+        step.check()
+    assert not np.isfinite(float(loss_sum.item()))  # never a plausible number

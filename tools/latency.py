@@ -72,3 +72,42 @@ for name, (x, pos, ei) in cases.items():
                 _ = loss.item()
             torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
         print(f"{name:36s} {mode:8s} median {1e3*np.median(ts[5:]):7.3f} ms  min {1e3*np.min(ts[5:]):7.3f} ms", flush=True)
+
+# The reference's superpixel regime: a NEW topology every optimizer step over the same node count
+# (utils/image_to_graph/image_to_graph_superpixel.py:31-66).  eager = what a changing topology cost before (host-bound);
+# captured / any topology = ONE hipGraph whose buffers hold a dummy node and spare edge slots, topology build inside the graph.
+from graphnet_classifier_amd.train import CapturedTrainStep, FlatParameters, FusedAdam  # noqa: E402
+graphs = [synthetic.superpixel_like_graphs(1, seed=2000 + k, shapes=((12, 12),)) for k in range(8)]
+graphs = [(g.x, g.pos, g.edge_index) for g in graphs]
+tmodel = CombinedModel(GraphNet(num_local_features=3, space_dim=2, out_channels=1, n_blocks=3), num_nodes=144, classes=2)
+tmodel.train()
+fopt = FusedAdam(FlatParameters(tmodel), lr=1e-3)
+crit = torch.nn.CrossEntropyLoss()
+label = torch.tensor(1)
+loss_sum = torch.zeros((), dtype=torch.float64, device="cuda:0")
+dev_graphs = [(x.cuda(), p.cuda(), e.cuda()) for x, p, e in graphs]
+labdev = label.cuda()
+ts = []
+for it in range(60):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    logits = tmodel(dev_graphs[it % 8])
+    loss = crit(logits, labdev)
+    fopt.zero_grad(); loss.backward(); fopt.step()
+    loss_sum += loss.detach().double()
+    torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+print(f"{'new topology every step (N=144)':36s} train/fused (eager)            median {1e3*np.median(ts[5:]):7.3f} ms", flush=True)
+cap = max(int(e.size(1)) for _, _, e in graphs)
+step = CapturedTrainStep(tmodel, fopt, crit, graphs[0], label, loss_sum, edge_capacity=(cap * 3 // 2 + 255) // 256 * 256)
+for src, tag in ((graphs, "host tensors in"), (dev_graphs, "device tensors in")):
+    ts = []
+    for it in range(60):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        step(src[it % 8], label)
+        torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    print(f"{'new topology every step (N=144)':36s} train/captured, any topology ({tag}) median {1e3*np.median(ts[5:]):7.3f} ms  "
+          f"(edge capacity {step.edge_capacity})", flush=True)
+try:
+    step.check()
+except IndexError:
+    print("flags:", step._status.tolist(), bool(step._range_flag), "loss_sum", float(loss_sum))
+    raise
