@@ -296,19 +296,48 @@ class CapturedForward:
     (optimized.py:42-47), so the whole launch sequence can be recorded once and replayed: new ``x`` / ``pos``
     are copied into the captured input buffers, one ``hipGraphLaunch`` runs every kernel.  Inference only
     (no autograd through a replay).
+
+    ``edge_capacity`` given: ANY topology over the same node count (superpixel graphs: a new region adjacency per image,
+    utils/image_to_graph/image_to_graph_superpixel.py:31-66).  The captured buffers hold extra dummy nodes with zero
+    features and ``edge_capacity`` edge slots, the unused tail of which are self-loops of the dummies (at most 8 each, so
+    no destination becomes a hub); the topology build - device flags, no host sync - is part of the graph, so a replay
+    sorts whatever edge list the buffer holds.  Dummy rows only talk to dummies and are dropped from the result, which is
+    therefore the plain forward's, bit for bit.  ``check()`` reads the flags of the last replay (ids outside the graph).
     """
 
-    def __init__(self, model: nn.Module, x: Tensor, pos: Tensor, edge_index: Tensor):
+    def __init__(self, model: nn.Module, x: Tensor, pos: Tensor, edge_index: Tensor, edge_capacity: int | None = None):
         gnet = model.graph_net if isinstance(model, CombinedModel) else model
         dev = require_gpu_param(next(model.parameters()), "CapturedForward")
         self.model, self.device = model, dev
-        self.x = x.to(device=dev, dtype=torch.float32).clone()
-        self.pos = pos.to(device=dev, dtype=torch.float32).clone()
-        self.topo = get_topology(edge_index, self.x.size(0), dev)  # host sync happens here, outside the capture
+        self.edge_capacity, self.num_nodes = edge_capacity, int(x.size(0))
+        if edge_capacity is None:
+            self.x = x.to(device=dev, dtype=torch.float32).clone()
+            self.pos = pos.to(device=dev, dtype=torch.float32).clone()
+            self.topo = get_topology(edge_index, self.x.size(0), dev)  # host sync happens here, outside the capture
 
-        def run():
-            y = gnet.forward_device(self.x, self.pos, self.topo)
-            return model.classifier(y.flatten()) if isinstance(model, CombinedModel) else y
+            def run():
+                y = gnet.forward_device(self.x, self.pos, self.topo)
+                return model.classifier(y.flatten()) if isinstance(model, CombinedModel) else y
+        else:
+            n, e = self.num_nodes, int(edge_index.size(1))
+            if e > edge_capacity:
+                raise ValueError(f"CapturedForward: {e} edges exceed edge_capacity {edge_capacity}")
+            dummies = max(1, (edge_capacity + 7) // 8)
+            self.x = torch.zeros(n + dummies, *x.shape[1:], dtype=torch.float32, device=dev)
+            self.pos = torch.zeros(n + dummies, *pos.shape[1:], dtype=torch.float32, device=dev)
+            self._tail = n + torch.arange(edge_capacity, dtype=torch.int64, device=dev) % dummies
+            self.edge_index = self._tail.repeat(2, 1)
+            self.x[:n].copy_(x)
+            self.pos[:n].copy_(pos)
+            self.edge_index[:, :e].copy_(edge_index)
+            self.topo, self._status = None, None
+            self._range_flag = torch.zeros((), dtype=torch.bool, device=dev)
+
+            def run():
+                topo = GraphTopology(self.edge_index, n + dummies, device=dev, validate="deferred")  # never the cache
+                self._status = topo.status  # the capture's own flags: every replay rewrites them
+                y = gnet.forward_device(self.x, self.pos, topo)[:n]
+                return model.classifier(y.flatten()) if isinstance(model, CombinedModel) else y
 
         with torch.no_grad():
             side = torch.cuda.Stream(device=dev)
@@ -321,12 +350,40 @@ class CapturedForward:
             with torch.cuda.graph(self.graph):
                 self.out = run()
 
-    def __call__(self, x: Tensor, pos: Tensor | None = None) -> Tensor:
-        self.x.copy_(x, non_blocking=True)
-        if pos is not None:
-            self.pos.copy_(pos, non_blocking=True)
+    def __call__(self, x: Tensor, pos: Tensor | None = None, edge_index: Tensor | None = None) -> Tensor:
+        if self.edge_capacity is None:
+            self.x.copy_(x, non_blocking=True)
+            if pos is not None:
+                self.pos.copy_(pos, non_blocking=True)
+        else:
+            n = self.num_nodes
+            if x.size(0) != n:
+                raise ValueError(f"CapturedForward: {x.size(0)} nodes, captured for {n}")
+            self.x[:n].copy_(x, non_blocking=True)
+            if pos is not None:
+                self.pos[:n].copy_(pos, non_blocking=True)
+            if edge_index is not None:
+                e = int(edge_index.size(1))
+                if e > self.edge_capacity:
+                    raise ValueError(f"CapturedForward: {e} edges exceed edge_capacity {self.edge_capacity}")
+                # ids in [n, n + dummies) would pass the topology build's range check but are not nodes of THIS graph
+                if e and not edge_index.is_cuda:
+                    if int(edge_index.max()) >= n or int(edge_index.min()) < 0:
+                        raise IndexError(f"edge_index has node ids outside [0, {n})")
+                elif e:
+                    self._range_flag |= (edge_index >= n).any()
+                self.edge_index[:, :e].copy_(edge_index, non_blocking=True)
+                self.edge_index[:, e:].copy_(self._tail[e:])
         self.graph.replay()
         return self.out
+
+    def check(self) -> None:
+        """``edge_capacity`` form: read the device flags of the last replayed topology build (one host sync) and raise the
+        IndexError of models/GNN.py:18-20 for node ids outside the graph (the output of such a replay is NaN)."""
+        status = getattr(self, "_status", None)
+        if status is not None and bool((status.any() | self._range_flag).item()):
+            self._range_flag.zero_()
+            raise IndexError(f"edge_index has node ids outside [0, {self.num_nodes})")
 
 
 # --------------------------------------------------------------------------- a8 read-out

@@ -106,6 +106,20 @@ for src, tag in ((graphs, "host tensors in"), (dev_graphs, "device tensors in"))
         torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
     print(f"{'new topology every step (N=144)':36s} train/captured, any topology ({tag}) median {1e3*np.median(ts[5:]):7.3f} ms  "
           f"(edge capacity {step.edge_capacity})", flush=True)
+from graphnet_classifier_amd.GNN import CapturedForward  # noqa: E402
+imodel = CombinedModel(GraphNet(num_local_features=3, space_dim=2, out_channels=1, n_blocks=3), num_nodes=144, classes=2).eval()
+for tag, runner in (("forward (eager)", None), ("forward/captured, any topology", CapturedForward(imodel, *graphs[0], edge_capacity=step.edge_capacity))):
+    ts = []
+    for it in range(60):
+        g = dev_graphs[it % 8]
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        if runner is None:
+            with torch.no_grad():
+                out = imodel(g)
+        else:
+            out = runner(*g)
+        torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    print(f"{'new topology every call (N=144)':36s} {tag:46s} median {1e3*np.median(ts[5:]):7.3f} ms", flush=True)
 try:
     step.check()
 except IndexError:
