@@ -57,6 +57,17 @@ def scatter_sum(src: Tensor, index: Tensor, dim: int = 0, dim_size: int | None =
 
 
 # --------------------------------------------------------------------------- a3 EdgeProcessor
+def _poison_if_deferred(topo: GraphTopology, out: Tensor) -> Tensor:
+    """Deferred validation (topology.set_validation): the topology's out-of-range flags have not been read back, and the
+    kernels ran on sanitised ids - a result computed from a bad ``edge_index`` must not look plausible (the reference raises
+    IndexError, models/GNN.py:18-20; ``check_deferred()`` raises it later).  NaN on the device when a flag is set."""
+    if not topo.deferred:
+        return out
+    if out.requires_grad or not out.is_contiguous():
+        return torch.where(topo.status.any(), torch.full_like(out, float("nan")), out)
+    return native.poison_if_flagged_(out, topo.status)  # inference: one launch that returns at once unless a flag is set
+
+
 class EdgeProcessor(nn.Module):
     def __init__(self, in_dim_node: int, in_dim_edge: int, hidden_dim: int = 128, hidden_layers: int = 2,
                  activation: str = "ReLU", initializer: None | str = None, norm_type: None | str = "LayerNorm"):
@@ -117,7 +128,7 @@ class NodeProcessor(nn.Module):
         x, edge_attr = (t.to(device=dev, dtype=torch.float32) for t in (x, edge_attr))
         topo = get_topology(edge_index, x.size(0), dev)
         agg = Fn.scatter_sum_csr(edge_attr, topo.rowptr, topo.perm, topo.col32, topo.num_nodes)
-        out = self.node_processor.forward_segments([(x, None), (agg, None)], residual=x)
+        out = _poison_if_deferred(topo, self.node_processor.forward_segments([(x, None), (agg, None)], residual=x))
         return out if back == dev else out.to(back)
 
     def forward_sorted(self, x: Tensor, topo: GraphTopology, edge_attr: Tensor, agg: Tensor | None = None) -> Tensor:
@@ -150,6 +161,7 @@ class MetaLayer(nn.Module):
         e_sorted = Fn.permute_rows(edge_attr, topo.perm, topo.inv_perm)
         x, e_sorted = self.forward_sorted(x, topo, e_sorted)
         edge_attr = Fn.permute_rows(e_sorted, topo.inv_perm, topo.perm)
+        x, edge_attr = _poison_if_deferred(topo, x), _poison_if_deferred(topo, edge_attr)
         if back != dev:
             x, edge_attr = x.to(back), edge_attr.to(back)
         return x, edge_attr, u
@@ -208,6 +220,7 @@ class GraphProcessor(nn.Module):
         topo = get_topology(edge_index, x.size(0), dev)
         x, e_sorted = self.forward_sorted(x, topo, Fn.permute_rows(edge_attr, topo.perm, topo.inv_perm))
         edge_attr = Fn.permute_rows(e_sorted, topo.inv_perm, topo.perm)
+        x, edge_attr = _poison_if_deferred(topo, x), _poison_if_deferred(topo, edge_attr)
         if back != dev:
             x, edge_attr = x.to(back), edge_attr.to(back)
         return x, edge_attr
@@ -270,12 +283,7 @@ class GraphNet(nn.Module):
             edge_attr = self.edge_encoder.forward_segments([(edge_attr, None)])           # :306
         out, _ = self.graph_processor.forward_sorted(out, topo, edge_attr)                # :307
         out = self.node_decoder.forward_segments([(out, None)])                           # :308
-        if topo.deferred:  # validation not read back yet: a bad edge_index must not yield a plausible result
-            if out.requires_grad or not out.is_contiguous():
-                out = torch.where(topo.status.any(), torch.full_like(out, float("nan")), out)
-            else:  # inference: one launch that returns at once unless a flag is set
-                out = native.poison_if_flagged_(out, topo.status)
-        return out
+        return _poison_if_deferred(topo, out)  # validation not read back yet: a bad edge_index must not yield a plausible result
 
     def forward(self, x, pos, edge_index):
         dev = require_gpu_param(self.node_encoder.model[0].weight, "GraphNet")

@@ -538,6 +538,19 @@ def test_deferred_validation_poisons_the_output_and_raises_at_the_check(G):
         with pytest.raises(IndexError):
             topology.check_deferred()
         topology.check_deferred()  # nothing pending any more
+        # the block-level entry points build a topology too: same rule (advisor finding of round 2)
+        block = m.graph_processor.blocks[0]
+        xn = torch.randn(batch.num_nodes, 32, device=DEV)
+        ea = torch.randn(ei.size(1), 32, device=DEV)
+        for grad in (False, True):
+            with torch.set_grad_enabled(grad):
+                topology.clear_topology_cache()
+                outs = list(block(xn, bad, ea)[:2]) + list(m.graph_processor(xn, bad, ea)) + [block.node_model(xn, bad, ea)]
+                assert all(bool(torch.isnan(o).all()) for o in outs)
+                okx, oke, _ = block(xn, ei, ea)
+                assert bool(torch.isfinite(okx).all()) and bool(torch.isfinite(oke).all())
+            with pytest.raises(IndexError):
+                topology.check_deferred()
     finally:
         topology.set_validation("sync")
         topology.clear_topology_cache()
