@@ -401,6 +401,31 @@ def test_captured_forward_for_any_topology_is_bit_identical_to_the_plain_forward
             cap.check()
 
 
+def test_captured_forward_for_any_topology_replays_the_general_sort_path(G):
+    """Edge lists too long for the LDS topology path (one graph of > 4096 padded edges): every replay runs the general path -
+    ONE gated kernel whose passes meet at a grid barrier, its arrival counter re-zeroed inside the graph - and still equals
+    the plain forward bit for bit."""
+    rng = np.random.default_rng(22)
+    n = 300
+    torch.manual_seed(6)
+    gnet = G.GraphNet(**{**dict(num_local_features=3, space_dim=2, out_channels=1, n_blocks=2), **{k: 32 for k in (
+        "out_dim_node", "out_dim_edge", "hidden_dim_node", "hidden_dim_edge", "hidden_dim_decoder", "hidden_dim_processor_node",
+        "hidden_dim_processor_edge")}})
+    graphs = []
+    for _ in range(4):
+        e = int(rng.integers(5000, 6000))
+        graphs.append((torch.from_numpy(rng.random((n, 3), dtype=np.float32)), torch.from_numpy((rng.random((n, 2)) * 32).astype(np.float32)),
+                       torch.from_numpy(rng.integers(0, n, size=(2, e)).astype(np.int64))))
+    cap = G.CapturedForward(gnet, *graphs[0], edge_capacity=8192)
+    for k in (1, 2, 3, 0, 2):
+        x, pos, ei = graphs[k]
+        got = cap(x, pos, ei).clone()
+        with torch.no_grad():
+            want = gnet(x.to(DEV), pos.to(DEV), ei.to(DEV))
+        assert torch.equal(got, want), k
+    cap.check()
+
+
 @pytest.mark.parametrize("kw", [
     dict(norm_type=None),
     dict(activation="Tanh"),
