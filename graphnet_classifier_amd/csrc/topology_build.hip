@@ -141,7 +141,8 @@ template <typename IdxT, bool WITH_ENDPOINTS>
 __global__ __launch_bounds__(NT) void topo_tile_sort(const IdxT* __restrict__ dst, const IdxT* __restrict__ src, int64_t E, int64_t N,
                                                      const int* __restrict__ P, const int* __restrict__ S, int num_tiles,
                                                      int* __restrict__ rowptr, int* __restrict__ perm, int* __restrict__ src_sorted,
-                                                     int* __restrict__ dst_sorted, int* __restrict__ status, int phase_limit) {
+                                                     int* __restrict__ dst_sorted, int* __restrict__ status, int phase_limit,
+                                                     unsigned* __restrict__ single_tile_bar) {
   __shared__ int skey[CAP];
   __shared__ int hist[KMAX];
   __shared__ unsigned short sidx[CAP];
@@ -154,6 +155,13 @@ __global__ __launch_bounds__(NT) void topo_tile_sort(const IdxT* __restrict__ ds
   const int n_win = (int)((E - wbase) < CAP ? (E - wbase) : CAP);
   const int last_tile = (int)((wbase + n_win - 1) / TT);  // last tile the window touches
   bool bad = false;
+  // ONE tile (a single small graph: the reference's one-graph-per-call regime): passes A and B are not launched - there is
+  // nothing in front of or behind the window - and this workgroup clears the flags and the general path's counter itself
+  const bool single = num_tiles == 1 && single_tile_bar != nullptr;
+  if (single) {
+    if (tid < 3) status[tid] = 0;
+    if (tid == 3) *single_tile_bar = 0;
+  }
   for (int k = tid; k < CAP; k += NT) skey[k] = k < n_win ? checked_id(dst[wbase + k], N, &bad) : IMAX;
   if (tid == 0) {
     sh_c0 = IMAX; sh_c1 = IMAX; sh_lo = IMAX; sh_hi = -1; sh_mprev = -1; sh_nbig = 0;
@@ -181,9 +189,9 @@ __global__ __launch_bounds__(NT) void topo_tile_sort(const IdxT* __restrict__ ds
   if (lane == 63) wmax[wave] = pmax;
   if (lane == 0) wmin[wave] = smin;
   __syncthreads();
-  int before = P[t];  // everything in front of the window
+  int before = single ? -1 : P[t];  // everything in front of the window
   for (int w = 0; w < wave; ++w) before = wmax[w] > before ? wmax[w] : before;
-  int after = S[last_tile];  // everything behind the window
+  int after = single ? IMAX : S[last_tile];  // everything behind the window
   for (int w = NT / 64 - 1; w > wave; --w) after = wmin[w] < after ? wmin[w] : after;
   int ex = __shfl_up(pmax, 1, 64);   // exclusive prefix max of the threads before this one
   ex = lane == 0 ? -1 : ex;
@@ -589,15 +597,19 @@ int build(const IdxT* src, const IdxT* dst, int64_t E, int64_t N, int* rowptr, i
     return GNC_ERR_WORKSPACE;
   }
   const int tiles = (int)((E + TT - 1) / TT);
-  topo_tile_minmax<IdxT><<<tiles, NT, 0, stream>>>(dst, E, N, w.tmin, w.tmax, status);
-  rc = gnc::check_launch("topo_tile_minmax");
-  if (rc) return rc;
-  topo_tile_scan<<<1, 1024, 0, stream>>>(w.tmin, w.tmax, tiles, w.P, w.S, w.bar);
-  rc = gnc::check_launch("topo_tile_scan");
-  if (rc) return rc;
+  // the general path's barrier counter; without a gated general path a dummy word of the workspace (tmin) takes the store
+  unsigned* single_bar = tiles == 1 ? (w.bar ? w.bar : reinterpret_cast<unsigned*>(w.tmin)) : nullptr;
+  if (tiles > 1) {
+    topo_tile_minmax<IdxT><<<tiles, NT, 0, stream>>>(dst, E, N, w.tmin, w.tmax, status);
+    rc = gnc::check_launch("topo_tile_minmax");
+    if (rc) return rc;
+    topo_tile_scan<<<1, 1024, 0, stream>>>(w.tmin, w.tmax, tiles, w.P, w.S, w.bar);
+    rc = gnc::check_launch("topo_tile_scan");
+    if (rc) return rc;
+  }
   const char* pl = getenv("GNC_TOPO_PHASE_LIMIT");  // developer probe: stop the sort kernel after phase n (timing only)
   topo_tile_sort<IdxT, WITH_ENDPOINTS><<<tiles, NT, 0, stream>>>(dst, src, E, N, w.P, w.S, tiles, rowptr, perm, src_sorted, dst_sorted,
-                                                               status, pl ? atoi(pl) : 0);
+                                                               status, pl ? atoi(pl) : 0, single_bar);
   rc = gnc::check_launch("topo_tile_sort");
   if (rc || !gated_fallback) return rc;
   // general path, gated on the device by status[2]: one launch
