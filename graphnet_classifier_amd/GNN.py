@@ -330,6 +330,9 @@ class CapturedForward:
             n, e = self.num_nodes, int(edge_index.size(1))
             if e > edge_capacity:
                 raise ValueError(f"CapturedForward: {e} edges exceed edge_capacity {edge_capacity}")
+            if model.training and any(isinstance(m, nn.modules.batchnorm._BatchNorm) for m in model.modules()):
+                # batch statistics span ALL rows: the dummy rows would enter them (eval mode normalises row by row)
+                raise NotImplementedError("CapturedForward(edge_capacity=...): a BatchNorm model must be in eval() mode")
             dummies = max(1, (edge_capacity + 7) // 8)
             self.x = torch.zeros(n + dummies, *x.shape[1:], dtype=torch.float32, device=dev)
             self.pos = torch.zeros(n + dummies, *pos.shape[1:], dtype=torch.float32, device=dev)

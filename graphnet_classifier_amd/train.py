@@ -192,6 +192,9 @@ class CapturedTrainStep:
             n, e = self.num_nodes, int(edge_index.size(1))
             if e > edge_capacity:
                 raise ValueError(f"CapturedTrainStep: {e} edges exceed edge_capacity {edge_capacity}")
+            if any(isinstance(m, nn.modules.batchnorm._BatchNorm) for m in model.modules()):
+                # batch statistics span ALL rows: the dummy rows would enter them (LayerNorm is per row and unaffected)
+                raise NotImplementedError("CapturedTrainStep(edge_capacity=...): not with BatchNorm layers (norm_type='BatchNorm1d')")
             if forward is None and not (hasattr(model, "graph_net") and hasattr(model, "classifier")):
                 raise TypeError("CapturedTrainStep(edge_capacity=...): pass forward= for a module that is not a CombinedModel")
             dummies = max(1, (edge_capacity + 7) // 8)
@@ -414,7 +417,8 @@ class _SampleStepper:
         if self.padded is not None and not self.padded.matches(sample) and sample[0].size(0) == self.padded.num_nodes:
             self.padded = None  # more edges than the capacity: capture again with room to spare
         if (self.padded is None and same_nodes and self._padded_captures < self.MAX_PADDED_CAPTURES
-                and hasattr(self.model, "graph_net") and hasattr(self.model, "classifier")):
+                and hasattr(self.model, "graph_net") and hasattr(self.model, "classifier")
+                and not any(isinstance(m, nn.modules.batchnorm._BatchNorm) for m in self.model.modules())):
             most = max(int(prev[2].size(1)), int(sample[2].size(1)))
             capacity = (most * 3 // 2 + 255) // 256 * 256
             self.padded = CapturedTrainStep(self.model, self.optimizer, self.criterion, sample, label, self.loss_sum,

@@ -317,6 +317,13 @@ def test_captured_step_restores_batchnorm_buffers(G):
     step(s0, l0)
     torch.cuda.synchronize()
     assert any(not torch.equal(v, before[k]) for k, v in m.state_dict().items() if "running_mean" in k)
+    # the any-topology form pads with dummy rows, which batch statistics would see: refused, and train() keeps such a
+    # model on eager steps when the topology changes
+    with pytest.raises(NotImplementedError):
+        CapturedTrainStep(m, opt, torch.nn.CrossEntropyLoss(), s0, l0, loss_sum, edge_capacity=1024)
+    with pytest.raises(NotImplementedError):
+        G.CapturedForward(m, *s0, edge_capacity=1024)
+    G.CapturedForward(m.eval(), *s0, edge_capacity=1024)  # eval mode normalises row by row: fine
 
 
 def _random_graph_dataset(n, count, seed, lo=150, hi=260):
