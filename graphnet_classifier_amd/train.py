@@ -158,7 +158,13 @@ class CapturedTrainStep:
     ``forward(model, x, pos, edge_index) -> logits`` replaces the default ``model((x, pos, edge_index))`` (a batched
     read-out, for instance); ``loss_scale`` multiplies the loss (``1 / global graph count`` of a sharded batch).
     With a process group of more than one rank the graph holds forward + backward + gradient pack, and every call
-    issues the ONE all-reduce and the fused Adam launch directly after the replay."""
+    issues the ONE all-reduce and the fused Adam launch directly after the replay.
+
+    ``edge_capacity=C``: the step is captured for ANY edge list of at most C edges over the sample's node count (a new
+    topology per sample: superpixel graphs) - see the comment in ``__init__``.  A custom ``forward`` then receives the PADDED
+    buffers (``x`` / ``pos`` with the dummy rows behind the first ``num_nodes``, ``edge_index`` [2, C]); it must build its
+    topology from them in every call (``GraphTopology(..., validate="deferred")``, never the cache) and read out the first
+    ``num_nodes`` rows only.  ``check()`` raises the IndexError of a replayed edge list with ids outside the graph."""
 
     def __init__(self, model: nn.Module, optimizer: FusedAdam, criterion, sample, label, loss_sum: torch.Tensor, *,
                  forward=None, loss_scale: float = 1.0, capture_error_mode: str = "global", edge_capacity: int | None = None):
