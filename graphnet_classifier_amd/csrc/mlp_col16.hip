@@ -691,10 +691,17 @@ extern "C" int gnc_mlp_dual_projection_f32(const float* x, int64_t ld_x, int64_t
                                            int64_t ld_wb, int32_t in_dim, int32_t out_dim, float* out_a, float* out_b, int64_t ld_out,
                                            void* stream) {
   static const bool off = getenv("GNC_NO_DUAL_PROJECTION") != nullptr;  // A/B switch
+  if (!off && x && wa && wb && out_a && out_b && rows > gnc_mlp::col16_max_rows() && out_dim <= 64) {
+    // a large batch at widths <= 64: the weights-resident kernel's DUAL instance (rows read once, both matrices resident)
+    bool launched = false;
+    const int rc = gnc_mlp::launch_resident_dual(x, ld_x, rows, wa, ld_wa, wb, ld_wb, in_dim, out_dim, out_a, out_b, ld_out,
+                                                 (hipStream_t)stream, &launched);
+    if (rc || launched) return rc;
+  }
   if (off || !x || !wa || !wb || !out_a || !out_b || rows < 1 || rows > gnc_mlp::col16_max_rows() || in_dim != 128 || out_dim != 128 ||
       ld_wa != ld_wb || ld_wa % 4 != 0 || ld_x % 4 != 0 || ld_out % 4 != 0 || !al16h(x) || !al16h(wa) || !al16h(wb) || !al16h(out_a) ||
       !al16h(out_b) || (int64_t)128 * ld_wa * 4 > 0x7fffffffll) {
-    gnc::set_error("gnc_mlp_dual_projection_f32: outside the small-batch projection shape (128 -> 128, 16-B rows)");
+    gnc::set_error("gnc_mlp_dual_projection_f32: outside the small-batch projection shape (128 -> 128, 16-B rows) and the large-batch one (widths 33..64)");
     return GNC_ERR_UNSUPPORTED;
   }
   ColPlan p = {};

@@ -768,6 +768,8 @@ inline int tiles_for(int width) {
 int validate_desc(const gnc_mlp_desc_t* d, bool check_ptrs);
 // resident-weights variant (mlp_resident.hip): returns GNC_ERR_UNSUPPORTED when the weights
 // do not fit in LDS, in which case the caller falls through to the streaming kernel
+int launch_resident_dual(const float* x, int64_t ld_x, int64_t rows, const float* wa, int64_t ld_wa, const float* wb, int64_t ld_wb,
+                         int in_dim, int out_dim, float* out_a, float* out_b, int64_t ld_out, hipStream_t stream, bool* launched);
 int launch_resident(const gnc_mlp_desc_t& d, int T, bool narrow_out, hipStream_t stream, bool* launched,
                     bool probe_only = false);
 // streaming FAST variant (mlp_stream.hip) for widths whose weights do not fit in LDS; same contract

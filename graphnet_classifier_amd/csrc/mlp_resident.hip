@@ -86,9 +86,12 @@ constexpr int RNT = RWAVES * 64;
 // and the dimensions themselves alive across the tile loop; here they are compile-time constants.
 // EF = 1: K6 as the prologue (gnc_mlp_desc_t.ef_pos): the rows of the only segment are computed from the positions of the
 // edge's endpoints (two coalesced id loads one tile ahead, two 8-B gathers per row and tile) instead of being read.
+// DUAL: TWO single-Linear projections of the same rows in one launch (the W-split's node-side products x Ws^T and x Wd^T,
+// models/GNN.py:58-61): the rows are read and staged once, both weight chunks are resident, the second matrix / output travel in
+// d.weight[1] / d.save_act[0] (a description built by gnc_mlp_dual_projection_f32, never by a caller).  No bias, no LayerNorm.
 // EF = 2: the only segment is a contiguous [rows, 3] table (the reference's node features, models/GNN.py:305): one 12-B load
 // per row and tile (lane & 31 = tile row) where it lies - no zero-padded [rows, 4] copy in front of the launch.
-template <int HT, int OT, int NMM, int NADD, bool RESREG, bool AGG = false, bool SAVE = false, bool FULL = false, int EF = 0>
+template <int HT, int OT, int NMM, int NADD, bool RESREG, bool AGG = false, bool SAVE = false, bool FULL = false, int EF = 0, bool DUAL = false>
 __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t d, const int num_wtiles,
                                                            const int total_chunks) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -125,6 +128,12 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
       const bool wv = (ldw % 4 == 0) && ((reinterpret_cast<uintptr_t>(d.weight[l]) & 15u) == 0);
       for (int c = 0; c * KC < d.in_dim[l]; ++c, ++chunk)
         stage_weights<WT * 32, RNT>(wres + chunk * CH, d.weight[l], ldw, d.out_dim[l], c * KC, d.in_dim[l], 16, wv, tid);
+    }
+    if constexpr (DUAL) {
+      const int ldw1 = ldw_of(d, 1);
+      const bool w1v = (ldw1 % 4 == 0) && ((reinterpret_cast<uintptr_t>(d.weight[1]) & 15u) == 0);
+      stage_weights<WT * 32, RNT>(wres + CH, d.weight[1], ldw1, d.out_dim[0], d.seg[0].wcol, d.seg[0].wcol + d.seg[0].width, 16,
+                                  w1v && (d.seg[0].wcol % 4 == 0), tid);
     }
   }
   __syncthreads();
@@ -369,6 +378,11 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
       PROBE(2);  // wait for the gathered rows + ADD step
     }
 
+    f32x16 hidb[DUAL ? HT : 1];
+    if constexpr (DUAL) {  // the second projection of the staged rows (same tile, the other resident weight chunk)
+      init_bias<HT>(hidb, pbuf, h);  // (no bias: zeros)
+      mma_chunk_from_lds<HT>(hidb, abuf, wres + CH, (sv[0].width + 7) >> 3, i, h);
+    }
     if (L == 1) {  // plain projection
       if (d.ln_gamma) layer_norm_tiles<HT>(hid, pbuf + L * PSTRIDE, pbuf + (L + 1) * PSTRIDE, out_dim, d.ln_eps, h);
       if constexpr (RESREG) {
@@ -511,6 +525,25 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
         }
       }
     }
+    if constexpr (DUAL) {  // the second output: through the wave's LDS tile like the first (launcher: whole 16-B pieces)
+      compiler_lds_barrier();
+      tiles_to_lds<HT>(hidb, abuf, i, h);
+      compiler_lds_barrier();
+      f32x4 outb[NP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) outb[p] = *reinterpret_cast<const f32x4*>(abuf + (p * 4 + rs) * LDSW + col_out);
+      if (col_out < out_dim) {
+        if (row0 + RPW <= rows) {
+          uint32_t r0b;
+          const __amdgpu_buffer_rsrc_t ow = full_tile_window(d.save_act[0], row0, rows, d.ld_out, &r0b);
+#pragma unroll
+          for (int p = 0; p < NP; ++p) hidden_window_store_s<true>(outb[p], out_lane_off + r0b, ow, (uint32_t)(p * 16 * d.ld_out));
+        } else {
+#pragma unroll
+          for (int p = 0; p < NP; ++p) hidden_window_store(outb[p], out_lane_off, row_window(d.save_act[0], row0 + 4 * p, rows, d.ld_out));
+        }
+      }
+    }
     compiler_lds_barrier();
     PROBE(6);  // epilogue: rows out
     wt = nwt;
@@ -524,12 +557,12 @@ __global__ __launch_bounds__(RNT) void mlp_resident_kernel(const gnc_mlp_desc_t 
   PROBE_END();
 }
 
-template <int HT, int OT, int NMM, int NADD, bool RESREG, bool AGG = false, bool SAVE = false, bool FULL = false, int EF = 0>
+template <int HT, int OT, int NMM, int NADD, bool RESREG, bool AGG = false, bool SAVE = false, bool FULL = false, int EF = 0, bool DUAL = false>
 int launch(const gnc_mlp_desc_t& d, int total_chunks, size_t smem, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
     int rc = gnc::check_hip(
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_resident_kernel<HT, OT, NMM, NADD, RESREG, AGG, SAVE, FULL, EF>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_resident_kernel<HT, OT, NMM, NADD, RESREG, AGG, SAVE, FULL, EF, DUAL>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
         "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc) return rc;
@@ -539,7 +572,7 @@ int launch(const gnc_mlp_desc_t& d, int total_chunks, size_t smem, hipStream_t s
   int64_t grid = gnc::ceil_div(num_wtiles, RWAVES);
   if (grid > gnc::num_cu()) grid = gnc::num_cu();  // one persistent workgroup per CU
   if constexpr (AGG) grid = gnc::num_cu();        // agg_fix has two entries for every wave of the full grid
-  mlp_resident_kernel<HT, OT, NMM, NADD, RESREG, AGG, SAVE, FULL, EF>
+  mlp_resident_kernel<HT, OT, NMM, NADD, RESREG, AGG, SAVE, FULL, EF, DUAL>
       <<<dim3((unsigned)grid), dim3(RNT), smem, stream>>>(d, (int)num_wtiles, total_chunks);
   return gnc::check_launch("mlp_resident_kernel");
 }
@@ -549,6 +582,41 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 }  // namespace
 
 extern "C" int gnc_mlp_agg_fix_len(void) { return 2 * gnc::num_cu() * RWAVES; }
+
+// Two projections of the same rows (x wa^T -> out_a, x wb^T -> out_b) for a large batch at widths <= 64: see DUAL above.
+int gnc_mlp::launch_resident_dual(const float* x, int64_t ld_x, int64_t rows, const float* wa, int64_t ld_wa, const float* wb,
+                                  int64_t ld_wb, int in_dim, int out_dim, float* out_a, float* out_b, int64_t ld_out,
+                                  hipStream_t stream, bool* launched) {
+  *launched = false;
+  static const bool disabled = getenv("GNC_MLP_NO_RESIDENT") != nullptr;
+  if (disabled || rows < 1 || rows >= INT32_MAX || in_dim < 1 || in_dim > KC || out_dim <= 32 || out_dim > KC || out_dim % 4 != 0 ||
+      ld_x % 4 != 0 || ld_x < in_dim || ld_out % 4 != 0 || ld_out < out_dim || ld_wa < in_dim || ld_wb < in_dim || ld_wa > INT32_MAX ||
+      ld_wb > INT32_MAX || ld_x > INT32_MAX || ld_out > INT32_MAX || !al16(x) || !al16(out_a) || !al16(out_b))
+    return GNC_OK;
+  gnc_mlp_desc_t d = {};
+  d.num_segments = 1;
+  d.num_linear = 1;
+  d.activation = GNC_ACT_RELU;
+  d.seg[0].ptr = x;
+  d.seg[0].width = in_dim;
+  d.seg[0].ld = (int32_t)ld_x;
+  d.seg[0].mode = GNC_SEG_MATMUL;
+  d.weight[0] = wa;
+  d.ld_weight[0] = (int32_t)ld_wa;
+  d.weight[1] = wb;  // DUAL: the second matrix and output ride in fields a single-Linear description leaves unused
+  d.ld_weight[1] = (int32_t)ld_wb;
+  d.in_dim[0] = in_dim;
+  d.out_dim[0] = out_dim;
+  d.in_dim[1] = in_dim;
+  d.out = out_a;
+  d.save_act[0] = out_b;
+  d.ld_out = (int32_t)ld_out;
+  d.rows = rows;
+  const int total_chunks = 2;
+  const size_t floats = (size_t)total_chunks * 2 * 32 * LDSW + (size_t)(1 + 2) * 2 * 32 + (size_t)RWAVES * RPW * LDSW;
+  *launched = true;
+  return launch<2, 2, 1, 0, false, false, false, false, 0, true>(d, total_chunks, floats * sizeof(float), stream);
+}
 
 int gnc_mlp::launch_resident(const gnc_mlp_desc_t& d, int T, bool narrow_out, hipStream_t stream, bool* launched,
                              bool probe_only) {

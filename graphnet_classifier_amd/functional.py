@@ -24,10 +24,11 @@ HIP_BACKWARD = os.environ.get("GNC_TORCH_BACKWARD") is None
 
 
 def _node_projections(x, w0, dn):
-    """(x Ws^T, x Wd^T) [N, H] each: the per-node halves of the W-split first Linear (models/GNN.py:58-61).  Two launches:
-    one launch over the stacked weight [Ws ; Wd] (x read once, [N, 2H] written, the halves as gather tables) measured no
-    faster on the same box (c3 8.14 / 8.29 vs 8.13 / 8.25 ms per step, c2 41.51 vs 41.55) and was dropped."""
-    return native.dual_projection(x, w0[:, :dn], w0[:, dn:2 * dn])  # (one launch for a small batch at 128 features)
+    """(x Ws^T, x Wd^T) [N, H] each: the per-node halves of the W-split first Linear (models/GNN.py:58-61).  ONE launch with two
+    output tables for a small batch at 128 features and for a large batch at widths <= 64 (c3: rows read once, both column
+    slices resident), two launches otherwise.  (One launch over the stacked weight [Ws ; Wd] writing ONE [N, 2H] table, the
+    halves as gather tables, measured no faster - c3 8.14 / 8.29 vs 8.13 / 8.25 ms per step, c2 41.51 vs 41.55 - and was dropped.)"""
+    return native.dual_projection(x, w0[:, :dn], w0[:, dn:2 * dn])
 
 
 class _ScatterSumCSR(torch.autograd.Function):

@@ -707,15 +707,20 @@ def dual_projection(x: torch.Tensor, wa: torch.Tensor, wb: torch.Tensor):
     _require_cuda(x, wa, wb)
     x, wa, wb = _rowmajor(x), _rowmajor(wa.detach()), _rowmajor(wb.detach())
     rows = x.size(0)
-    if (1 <= rows <= lib.gnc_mlp_small_batch_max_rows() and wa.shape == wb.shape and wa.size(1) == x.size(1) == 128
-            and wa.size(0) == 128 and _ld(wa) == _ld(wb) and os.environ.get("GNC_NO_DUAL_PROJECTION") is None):
-        oa = torch.empty(rows, 128, dtype=torch.float32, device=x.device)
-        ob = torch.empty(rows, 128, dtype=torch.float32, device=x.device)
+    k, m = x.size(1), wa.size(0)
+    small = 1 <= rows <= lib.gnc_mlp_small_batch_max_rows() and k == m == 128
+    # a large batch at widths <= 64 (c3): the weights-resident kernel's dual instance - the rows are read once
+    large = rows > lib.gnc_mlp_small_batch_max_rows() and k <= 64 and 32 < m <= 64 and m % 4 == 0 and _ld(x) % 4 == 0 \
+        and x.data_ptr() % 16 == 0
+    if ((small or large) and wa.shape == wb.shape and wa.size(1) == k and _ld(wa) == _ld(wb)
+            and os.environ.get("GNC_NO_DUAL_PROJECTION") is None):
+        oa = torch.empty(rows, m, dtype=torch.float32, device=x.device)
+        ob = torch.empty(rows, m, dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
-            rc = _launch("mlp_fused_in128_h128_out128_L1x2", oa,
+            rc = _launch(f"mlp_fused_in{k}_h{m}_out{m}_L1x2", oa,
                          lambda: lib.gnc_mlp_dual_projection_f32(x.data_ptr(), _ld(x), rows, wa.data_ptr(), _ld(wa), wb.data_ptr(), _ld(wb),
-                                                                 128, 128, oa.data_ptr(), ob.data_ptr(), _ld(oa), _stream(x)),
-                         2.0 * rows * 2 * 128 * 128)
+                                                                 k, m, oa.data_ptr(), ob.data_ptr(), _ld(oa), _stream(x)),
+                         2.0 * rows * 2 * k * m)
         if rc == 0:
             return oa, ob
     return mlp_forward([(x, None)], [wa], [None]), mlp_forward([(x, None)], [wb], [None])

@@ -326,6 +326,27 @@ def test_three_column_input_and_weights_are_read_where_they_lie(native, rows):
     assert max_abs(got.cpu(), O.mlp_forward(sd, "m", x.cpu())) <= 1e-5
 
 
+@pytest.mark.parametrize("k,m,rows", [(64, 64, 100000), (64, 64, 33 * 1024 + 5), (48, 40, 70001), (64, 36, 40000)])
+def test_dual_projection_of_a_large_batch_is_bit_identical_to_two_launches(native, k, m, rows):
+    """The W-split's node-side products x Ws^T and x Wd^T (models/GNN.py:58-61) in ONE launch of the weights-resident kernel
+    (rows read once, both matrices resident; column slices of the nn.Linear matrix read where they lie)."""
+    rng = np.random.default_rng(rows + k)
+    x = torch.from_numpy(rng.standard_normal((rows, k)).astype(np.float32)).to(DEV)
+    w0 = torch.from_numpy(rng.standard_normal((m, 2 * k + 8)).astype(np.float32)).to(DEV)
+    wa, wb = w0[:, :k], w0[:, k:2 * k]
+    names = []
+    native.set_kernel_timers(type("T", (), {"launch": lambda self, name, t, fn, work=0.0: (names.append(name), fn())[1]})())
+    try:
+        a, b = native.dual_projection(x, wa, wb)
+    finally:
+        native.set_kernel_timers(None)
+    assert names == [f"mlp_fused_in{k}_h{m}_out{m}_L1x2"], names
+    ra = native.mlp_forward([(x, None)], [wa], [None])
+    rb = native.mlp_forward([(x, None)], [wb], [None])
+    assert torch.equal(a, ra) and torch.equal(b, rb)
+    assert max_abs(a.cpu(), x.cpu() @ wa.cpu().t()) <= 1e-4 and max_abs(b.cpu(), x.cpu() @ wb.cpu().t()) <= 1e-4
+
+
 def test_edge_encoder_k6_prologue_declines_what_it_does_not_serve(native):
     rng = np.random.default_rng(5)
     n = 100
