@@ -273,9 +273,11 @@ int gnc_mlp_projection_t2_f32(const float* a, int64_t ld_a, const float* b, int6
                               int32_t hidden, int32_t dn, float* out, int64_t ld_out, void* stream);
 int64_t gnc_mlp_small_batch_max_rows(void); /* the row limit of the small-batch forward kernel (128 x CUs unless overridden) */
 /* ABI 18: out_a = x wa^T and out_b = x wb^T (no bias) over the same row-ordered x [rows, in_dim] in ONE launch: the two
- * node-side products of the W-split first Linear (models/GNN.py:58-61 formed once per node).  Only the small-batch projection
- * shape (in_dim = out_dim = 128, rows within the small-batch limit, 16-B aligned rows, ld_wa == ld_wb): GNC_ERR_UNSUPPORTED
- * otherwise, nothing launched - issue two gnc_mlp_forward_f32 launches then. */
+ * node-side products of the W-split first Linear (models/GNN.py:58-61 formed once per node).  Two shapes: the small-batch
+ * projection (in_dim = out_dim = 128, rows within the small-batch limit, 16-B aligned rows, ld_wa == ld_wb) and - since ABI 19 -
+ * a batch above that limit at in_dim <= 64, out_dim 36..64 (a multiple of 4) on the weights-resident kernel (rows read and
+ * staged once, both matrices resident in LDS, read where they lie whatever their row stride).  GNC_ERR_UNSUPPORTED otherwise,
+ * nothing launched - issue two gnc_mlp_forward_f32 launches then. */
 int gnc_mlp_dual_projection_f32(const float* x, int64_t ld_x, int64_t rows, const float* wa, int64_t ld_wa, const float* wb,
                                 int64_t ld_wb, int32_t in_dim, int32_t out_dim, float* out_a, float* out_b, int64_t ld_out,
                                 void* stream);
