@@ -84,6 +84,30 @@ def test_g4_graphnet(name):
     assert max_abs(y64, t(g["y"])) < 1e-5
 
 
+@pytest.mark.parametrize("name", ["g4_graphnet_tiny.npz", "g4_graphnet_default.npz"])
+def test_padding_with_dummy_nodes_and_self_loops_leaves_the_graph_untouched(name):
+    """What the any-topology captures rely on (graphnet_classifier_amd.train.CapturedTrainStep(edge_capacity=...),
+    GNN.CapturedForward(edge_capacity=...)): extra nodes with zero features whose only edges are their own self-loops never
+    reach a real node, so the reference's arithmetic on the padded graph gives the golden's outputs for the real nodes - the
+    same bits, since every real destination still sums the same rows in the same order (the padding sorts behind them)."""
+    g = load_golden(name)
+    sd = sub_state_dict(g, "sd/")
+    x, pos, ei = t(g["x"]), t(g["pos"]), t(g["edge_index"])
+    n, e = x.size(0), ei.size(1)
+    capacity = (e * 3 // 2 + 255) // 256 * 256
+    dummies = (capacity + 7) // 8
+    tail = n + torch.arange(capacity, dtype=ei.dtype) % dummies
+    ei_pad = tail.repeat(2, 1)
+    ei_pad[:, :e] = ei
+    x_pad = torch.cat([x, torch.zeros(dummies, x.size(1))])
+    pos_pad = torch.cat([pos, torch.zeros(dummies, pos.size(1))])
+    y_pad = O.graphnet_forward(sd, x_pad, pos_pad, ei_pad)
+    y = O.graphnet_forward(sd, x, pos, ei)
+    assert torch.equal(y_pad[:n], y) and max_abs(y_pad[:n], t(g["y"])) < 1e-5
+    assert bool(torch.isfinite(y_pad).all())
+    assert int(torch.bincount(ei_pad[1, e:], minlength=n + dummies).max()) <= 8  # no dummy becomes a hub
+
+
 def test_g4_graphnet_shipped_checkpoint():
     g = load_golden("g4_graphnet_ckpt.npz")
     sd = sub_state_dict(g, "sd/")
