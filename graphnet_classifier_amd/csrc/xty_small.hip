@@ -15,12 +15,21 @@ using namespace gnc_mlp;
 
 namespace {
 
-constexpr int XW = 4;  // waves per workgroup = row splits
 
 struct XJobs {
   gnc_xty_job_t j[GNC_XTY_MAX_JOBS];
 };
 
+// Row splits of ONE job: a function of its own row count only, so that a job's bits do not depend on which other jobs share
+// its launch (a launch runs max-over-jobs waves per workgroup; the waves a job does not use contribute zeros).  The launch is
+// latency-bound (two dword loads per MFMA, a few hundred workgroups on the chip): beyond a thousand rows more waves per tile -
+// more loads in flight - are what it needs.  Captured training step of R x R pixel graphs with 4 / 8 / 16 splits everywhere
+// (tools/latency_sizes.py, same box): R = 32 0.514 / 0.490 / 0.491 ms, R = 64 1.069 / 0.904 / 0.817, R = 96 1.678 / 1.516 /
+// 1.474, R = 128 (the reference's default image) 2.403 / 2.145 / 2.155; N = 144: equal.
+__host__ __device__ inline int xty_splits(int64_t rows) { return rows >= 4096 ? 16 : (rows >= 1024 ? 8 : 4); }
+
+// XW: waves per workgroup (>= the splits of every job of the launch)
+template <int XW>
 __global__ __launch_bounds__(XW * 64) void xty_small_kernel(const XJobs js) {
   __shared__ float part[XW][64 * 4];
   __shared__ float csum[XW][64];
@@ -35,11 +44,12 @@ __global__ __launch_bounds__(XW * 64) void xty_small_kernel(const XJobs js) {
     if ((int)blockIdx.x * 64 >= M) return;
     const __amdgpu_buffer_rsrc_t wa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(jb.a), 0, (int)(((int64_t)(rows - 1) * jb.lda + M) * 4), 0x00020000);
     float s = 0.f;
-    for (int p0 = w; p0 < rows; p0 += XW * 8) {
+    constexpr int XS1 = 4;  // four splits whatever the launch's wave count
+    for (int p0 = w; w < XS1 && p0 < rows; p0 += XS1 * 8) {
       float v[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u)  // rows past the end are outside the window: zeros
-        v[u] = c < M ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wa, (uint32_t)(((int64_t)(p0 + u * XW) * jb.lda + c) * 4), 0, 0)) : 0.f;
+        v[u] = c < M ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wa, (uint32_t)(((int64_t)(p0 + u * XS1) * jb.lda + c) * 4), 0, 0)) : 0.f;
 #pragma unroll
       for (int u = 0; u < 8; ++u) s += v[u];
     }
@@ -56,15 +66,16 @@ __global__ __launch_bounds__(XW * 64) void xty_small_kernel(const XJobs js) {
   const __amdgpu_buffer_rsrc_t wa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(jb.a), 0, (int)(((int64_t)(rows - 1) * jb.lda + M) * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t wb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(jb.b), 0, (int)(((int64_t)(rows - 1) * jb.ldb + K) * 4), 0x00020000);
   const bool aok = m0 + i < M, bok = k0 + i < K;
-  // wave w takes the row groups w, w + XW, ...; eight groups (32 rows) per iteration, all 16 loads in flight
+  // wave w (< xs, the job's splits) takes the row groups w, w + xs, ...; eight groups (32 rows) per iteration, all 16 loads in flight
+  const int xs = xty_splits(rows);
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   float asum = 0.f;
   const uint32_t lda4 = (uint32_t)jb.lda * 4u, ldb4 = (uint32_t)jb.ldb * 4u;
-  for (int r0 = 4 * w; r0 < rows; r0 += 4 * XW * 8) {
+  for (int r0 = 4 * w; w < xs && r0 < rows; r0 += 4 * xs * 8) {
     float av[8], bv[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const uint32_t r = (uint32_t)(r0 + u * 4 * XW + g);
+      const uint32_t r = (uint32_t)(r0 + u * 4 * xs + g);
       av[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wa, r * lda4 + (uint32_t)(m0 + i) * 4u, 0, 0));
       bv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wb, r * ldb4 + (uint32_t)(k0 + i) * 4u, 0, 0));
     }
@@ -132,6 +143,12 @@ extern "C" int gnc_xty_small_f32(const gnc_xty_job_t* jobs, int32_t njobs, void*
     gx = tiles > gx ? tiles : gx;
     js.j[q] = j;
   }
-  xty_small_kernel<<<dim3((unsigned)gx, (unsigned)njobs), dim3(XW * 64), 0, (hipStream_t)stream_>>>(js);
+  int xw = 4;  // waves per workgroup: the largest split count among the jobs
+  for (int q = 0; q < njobs; ++q)
+    if (jobs[q].kind == 0 && xty_splits(jobs[q].rows) > xw) xw = xty_splits(jobs[q].rows);
+  const dim3 grid((unsigned)gx, (unsigned)njobs);
+  if (xw >= 16) xty_small_kernel<16><<<grid, dim3(16 * 64), 0, (hipStream_t)stream_>>>(js);
+  else if (xw >= 8) xty_small_kernel<8><<<grid, dim3(8 * 64), 0, (hipStream_t)stream_>>>(js);
+  else xty_small_kernel<4><<<grid, dim3(4 * 64), 0, (hipStream_t)stream_>>>(js);
   return gnc::check_launch("xty_small_kernel");
 }

@@ -14,15 +14,16 @@ from graphnet_classifier_amd.image_to_graph import create_grid_edges_optimized  
 from graphnet_classifier_amd.train import CapturedTrainStep, FlatParameters, FusedAdam  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+R = int(sys.argv[2]) if len(sys.argv) > 2 else 32  # pixel graph R x R (128 = the reference's default image size, main.py)
 torch.manual_seed(0)
-ei = create_grid_edges_optimized(32, 32).cpu()
-rr, cc = np.meshgrid(np.arange(32), np.arange(32), indexing="ij")
-x = torch.rand(1024, 3) * 255
+ei = create_grid_edges_optimized(R, R).cpu()
+rr, cc = np.meshgrid(np.arange(R), np.arange(R), indexing="ij")
+x = torch.rand(R * R, 3) * 255
 pos = torch.from_numpy(np.stack([rr.ravel(), cc.ravel()], 1).astype(np.float32))
 label = torch.tensor(1)
 side = torch.cuda.Stream()
 with torch.cuda.stream(side):
-    model = CombinedModel(GraphNet(num_local_features=3, space_dim=2, out_channels=1, n_blocks=3), num_nodes=1024, classes=2)
+    model = CombinedModel(GraphNet(num_local_features=3, space_dim=2, out_channels=1, n_blocks=3), num_nodes=R * R, classes=2)
     model.train()
     opt = FusedAdam(FlatParameters(model), lr=1e-3)
     loss_sum = torch.zeros((), dtype=torch.float64, device="cuda:0")
